@@ -1,0 +1,193 @@
+/*
+ * moai_hip.h -- C ABI of the MI355X-native RNS-CKKS evaluator hot path.
+ *
+ * This is the drop-in boundary: everything MOAI's seal::Evaluator needs for ciphertext arithmetic,
+ * as plain C entry points over device pointers.  The host-side seal:: shim (and any other binding:
+ * ctypes, cgo, JNI) sits above this header; nothing below it is visible to callers.
+ *
+ * Each entry point names the reference interface it replaces.  Paths are relative to the
+ * reference checkout; SEAL/ = thirdparty/SEAL-4.1-bs/native/src/seal/.
+ *
+ * Conventions
+ *   - All residue data is uint64_t in the reference's own layout [poly][rns prime][coefficient]
+ *     (SEAL/ciphertext.h:337-349), with an optional leading batch dimension.  Pointers are DEVICE
+ *     pointers unless a parameter is documented "host".
+ *   - Inputs are canonical residues in [0, q_i); outputs are canonical residues, bit-identical to
+ *     the reference CPU path on the same inputs.
+ *   - A data level with L primes uses context primes [0, L); the key level is all k primes and
+ *     prime k-1 is the special prime (SEAL/context.cpp:455-522).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work and
+ *     return; they never synchronise the device.  Workspace is drawn from the context's arena,
+ *     which grows (hipMalloc) only outside stream capture -- call moai_ctx_reserve first when
+ *     capturing into a hipGraph.
+ *   - Return value: 0 on success, a negative MOAI_E* code otherwise; moai_last_error() gives the
+ *     message (thread local).  No exceptions cross this boundary: the C++ shim re-creates the
+ *     reference's exceptions (std::invalid_argument / std::logic_error / std::out_of_range)
+ *     BEFORE enqueueing, as the reference raises them synchronously.
+ */
+#ifndef MOAI_HIP_H
+#define MOAI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOAI_OK 0
+#define MOAI_EINVAL (-1)   /* bad argument (the shim maps it to std::invalid_argument) */
+#define MOAI_ELOGIC (-2)   /* unsupported parameters (std::logic_error)                */
+#define MOAI_ERANGE (-3)   /* index out of range (std::out_of_range)                   */
+#define MOAI_EHIP (-4)     /* HIP runtime failure                                      */
+#define MOAI_ENOMEM (-5)
+
+#define MOAI_MAX_RNS 64    /* largest number of RNS rows one call may address */
+
+typedef struct moai_ctx moai_ctx;
+
+const char *moai_last_error(void);
+int moai_version(void);
+
+/* ---- context: per-prime tables on the device -------------------------------------------------
+ * Replaces SEALContext's per-level ContextData precomputation for the hot path
+ * (SEAL/context.cpp:422-522, NTTTables::initialize SEAL/util/ntt.cpp:241-300, RNSTool
+ * inv_q_last_mod_q SEAL/util/rns.cpp:769-775, Modulus::const_ratio SEAL/modulus.cpp:36-77).
+ * Tables are shared per prime, not duplicated per level.  primes: host, k entries, each an NTT
+ * prime (= 1 mod 2N) below 2^61.  coeff_count_power in [1, 16].
+ */
+int moai_ctx_create(int coeff_count_power, const uint64_t *primes, size_t k, int device, moai_ctx **out);
+void moai_ctx_destroy(moai_ctx *ctx);
+int moai_ctx_reserve(moai_ctx *ctx, size_t workspace_bytes);
+size_t moai_ctx_coeff_count(const moai_ctx *ctx);
+size_t moai_ctx_prime_count(const moai_ctx *ctx);
+/* psi = minimal primitive 2N-th root of prime i (NTTTables::get_root) */
+uint64_t moai_ctx_root(const moai_ctx *ctx, size_t prime);
+
+/* ---- memory / streams (the device arena behind seal::DynArray / MemoryPool, SEAL/dynarray.h) -- */
+int moai_malloc(void **dptr, size_t bytes);
+int moai_free(void *dptr);
+int moai_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
+int moai_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
+int moai_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int moai_memset_zero(void *dst, size_t bytes, void *stream);
+int moai_stream_create(void **stream);
+int moai_stream_destroy(void *stream);
+int moai_stream_sync(void *stream);
+
+/* ---- negacyclic NTT ----------------------------------------------------------------------------
+ * data: uint64[n_poly][L][N] in place.  Row (p, r) is transformed under context prime
+ * prime_index[r] (host array of L entries) or prime r when prime_index is NULL.
+ * forward:  natural order in -> bit-reversed order out, canonical [0,q)
+ *           (ntt_negacyclic_harvey, SEAL/util/ntt.cpp:408-437; Evaluator::transform_to_ntt_inplace
+ *           SEAL/evaluator.cpp:2468-2514)
+ * inverse:  bit-reversed in -> natural out, scaled by N^-1, canonical
+ *           (inverse_ntt_negacyclic_harvey, SEAL/util/ntt.cpp:453-475;
+ *           Evaluator::transform_from_ntt_inplace SEAL/evaluator.cpp:2516-2561)
+ */
+int moai_ntt_forward(moai_ctx *ctx, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
+                     void *stream);
+int moai_ntt_inverse(moai_ctx *ctx, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
+                     void *stream);
+
+/* ---- element-wise RNS polynomial arithmetic (SEAL/util/polyarithsmallmod.cpp) -------------------
+ * All operate on uint64[n_poly][L][N] with row r under prime r; out may alias an input.
+ */
+/* add_poly_coeffmod :43-86 / Evaluator::add_inplace SEAL/evaluator.cpp:155-240 */
+int moai_add(moai_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
+             void *stream);
+/* sub_poly_coeffmod :88-133 / Evaluator::sub_inplace SEAL/evaluator.cpp:263-350 */
+int moai_sub(moai_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
+             void *stream);
+/* negate_poly_coeffmod polyarithsmallmod.h:77-106 / Evaluator::negate_inplace SEAL/evaluator.cpp:130-153 */
+int moai_negate(moai_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n_poly, size_t L, void *stream);
+/*
+ * dyadic_product_coeffmod :226-278.  a: [n_poly][L][N]; b: [n_poly_b][L][N] with n_poly_b == n_poly
+ * or n_poly_b == 1 (broadcast: Evaluator::multiply_plain_ntt SEAL/evaluator.cpp:2336-2373 multiplies
+ * every ciphertext polynomial by the one plaintext).
+ */
+int moai_dyadic_mul(moai_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly,
+                    size_t n_poly_b, size_t L, void *stream);
+/*
+ * multiply_poly_scalar_coeffmod :197-224 with one scalar per RNS row (host array scalars[L], any
+ * uint64; reduced mod q_r first like polyarithsmallmod.h:209-217).  This is multiply_plain by a
+ * scalar-encoded plaintext, whose rows are constant (SEAL/ckks.cpp:131-150), without materialising
+ * N*L words.
+ */
+int moai_mul_scalar_rows(moai_ctx *ctx, const uint64_t *a, const uint64_t *scalars, uint64_t *out, size_t n_poly,
+                         size_t L, void *stream);
+/* add_poly_scalar_coeffmod :135-164, one scalar per row (add_plain of a scalar-encoded plaintext
+ * touches polynomial 0 only: Evaluator::add_plain_inplace SEAL/evaluator.cpp:2014-2018). */
+int moai_add_scalar_rows(moai_ctx *ctx, const uint64_t *a, const uint64_t *scalars, uint64_t *out, size_t n_poly,
+                         size_t L, void *stream);
+
+/* ---- ciphertext products -------------------------------------------------------------------------
+ * Evaluator::ckks_multiply SEAL/evaluator.cpp:770-909, size 2 x size 2 -> size 3:
+ * out[b] = (x0*y0, x0*y1 + x1*y0, x1*y1).  x, y: [batch][2][L][N]; out: [batch][3][L][N]
+ * (out must not alias x or y).
+ */
+int moai_ct_multiply(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t L, size_t batch,
+                     void *stream);
+/* Evaluator::ckks_square SEAL/evaluator.cpp:1223-1282: (x0^2, 2 x0 x1, x1^2) */
+int moai_ct_square(moai_ctx *ctx, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream);
+
+/* ---- level changes ---------------------------------------------------------------------------------
+ * Evaluator::rescale_to_next SEAL/evaluator.cpp:1682-1720 -> mod_switch_scale_to_next :1402-1481 ->
+ * RNSTool::divide_and_round_q_last_ntt_inplace SEAL/util/rns.cpp:830-901.
+ * in: [batch][size][L][N] -> out: [batch][size][L-1][N]; in is preserved; out may not alias in.
+ */
+int moai_rescale(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
+                 void *stream);
+/* Evaluator::mod_switch_drop_to_next SEAL/evaluator.cpp:1483-1546 applied `drop` times:
+ * in: [batch][size][L][N] -> out: [batch][size][L-drop][N].  out == in is allowed (compacts in place). */
+int moai_mod_drop(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,
+                  size_t batch, void *stream);
+
+/* ---- Galois automorphism and key switching -----------------------------------------------------------
+ * GaloisTool::apply_galois_ntt SEAL/util/galois.cpp:192-218 with the table of :18-51:
+ * out[p][r][i] = in[p][r][table[i]].  galois_elt odd, < 2N.  out must not alias in.
+ */
+int moai_galois_permute(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n_poly, size_t L,
+                        uint32_t galois_elt, void *stream);
+/* GaloisTool::get_elt_from_step SEAL/util/galois.cpp:53-95 (generator 5 in this fork,
+ * SEAL/util/galois.h:169).  Returns 0 and sets the error for |step| >= N/2. */
+uint32_t moai_galois_elt_from_step(const moai_ctx *ctx, int step);
+/*
+ * Evaluator::switch_key_inplace SEAL/evaluator.cpp:2724-3020 (CKKS branch):
+ *   ct[b] (2 polys, NTT form, L primes) += ModDown_p( sum_J NTT_{q_I}([INTT(target[b]_J)]_{q_I}) (*) key[J][.][I] )
+ * ct: [batch][2][L][N] in place; target: [batch][L][N] (NTT form, not modified);
+ * key: uint64[k-1][2][k][N] -- the reference's KSwitchKeys entry, vector<PublicKey> of k-1 size-2
+ * ciphertexts at the key level (SEAL/kswitchkeys.h:340, keygenerator.cpp:303-336) flattened.
+ * Every ciphertext of the batch is switched with the same key.
+ */
+int moai_switch_key(moai_ctx *ctx, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,
+                    size_t batch, void *stream);
+/* Evaluator::relinearize_internal SEAL/evaluator.cpp:1345-1400 for size 3 -> 2:
+ * ct3: [batch][3][L][N]; out: [batch][2][L][N] (may not alias ct3). */
+int moai_relinearize(moai_ctx *ctx, const uint64_t *ct3, const uint64_t *relin_key, uint64_t *out, size_t L,
+                     size_t batch, void *stream);
+/* Evaluator::apply_galois_inplace SEAL/evaluator.cpp:2563-2665 (rotate_vector / complex_conjugate
+ * with the key present, rotate_internal :2667-2697): ct: [batch][2][L][N] in place. */
+int moai_apply_galois(moai_ctx *ctx, uint64_t *ct, size_t L, uint32_t galois_elt, const uint64_t *galois_key,
+                      size_t batch, void *stream);
+
+/* ---- MOAI-owned integer kernel ---------------------------------------------------------------------------
+ * Bootstrapper::modraise_inplace include/source/bootstrapping/Bootstrapper.cpp:2938-2992:
+ * in: [batch][2][1][N] (NTT form under prime 0) -> out: [batch][2][L_out][N] (NTT form). */
+int moai_modraise(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream);
+
+/* ---- measurement support -----------------------------------------------------------------------------------
+ * Average duration in milliseconds of the NTT kernels of the last moai_ntt_* call recorded with
+ * HIP events on the caller's stream is not provided here; callers time with their own events
+ * around the calls (bench.py does).  moai_device_info fills name (<= 255 chars) and CU count. */
+int moai_device_info(int device, char *name, size_t name_cap, int *compute_units, size_t *hbm_bytes);
+/* hipEvent helpers so that pure-C / ctypes callers can time the stream the kernels run on */
+int moai_event_create(void **event);
+int moai_event_destroy(void *event);
+int moai_event_record(void *event, void *stream);
+int moai_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+// common.h -- shared declarations of the MI355X evaluator library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/moai_hip.h"
+
+namespace moai {
+
+// One precomputed power of psi with its Shoup quotient floor(w * 2^64 / q)
+// (the role of SEAL's MultiplyUIntModOperand, SEAL/util/uintarithsmallmod.h:255-286).
+struct alignas(16) Tw
+{
+    uint64_t w;
+    uint64_t wq;
+};
+
+// Per-prime constants, one 128-byte record per prime in device memory.
+struct alignas(16) PrimeConst
+{
+    uint64_t q;        // modulus
+    uint64_t q2;       // 2q
+    uint64_t cr0;      // floor(2^128 / q), low word   (Modulus::const_ratio, SEAL/modulus.cpp:36-77)
+    uint64_t cr1;      //                   high word
+    Tw ninv;           // N^-1 mod q                     (NTTTables::inv_degree_modulo, ntt.cpp:290-296)
+    Tw ninv_w1;        // N^-1 * inv_tw[1] mod q: last inverse stage with the scaling folded in
+    uint64_t pad[8];
+};
+
+// Row -> context-prime map passed by value to kernels (rows of one RNS polynomial).
+struct RowMap
+{
+    uint16_t idx[MOAI_MAX_RNS];
+};
+
+int set_error(int code, const char *fmt, ...);
+
+#define MOAI_HIP_CHECK(expr)                                                                   \
+    do                                                                                         \
+    {                                                                                          \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+        {                                                                                      \
+            return ::moai::set_error(MOAI_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                     __FILE__, __LINE__);                                      \
+        }                                                                                      \
+    } while (0)
+
+#define MOAI_LAUNCH_CHECK() MOAI_HIP_CHECK(hipGetLastError())
+
+} // namespace moai
+
+// The opaque context of the C ABI.
+struct moai_ctx
+{
+    int device = 0;
+    int logn = 0;
+    size_t n = 0;
+    size_t k = 0;
+    int num_cu = 256;
+    std::vector<uint64_t> primes;      // host copies
+    std::vector<uint64_t> roots;       // psi per prime
+    std::vector<moai::PrimeConst> pc_host;
+    moai::Tw *fwd_tw = nullptr;        // [k][N]: index m+i = psi^bitrev(m+i)        (ntt.cpp:269-278)
+    moai::Tw *inv_tw = nullptr;        // [k][N]: index m+i = psi^-bitrev(m+i) (same indexing as fwd)
+    moai::PrimeConst *pc = nullptr;    // [k]
+    // inv_q_last_mod_q[l][i] = q_l^-1 mod q_i as Shoup operands, l in [1,k), i < l  (rns.cpp:769-775)
+    moai::Tw *inv_qlast = nullptr;     // [k][k]
+    std::vector<moai::Tw> inv_qlast_host;
+    // workspace arena
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    // Galois permutation tables, built lazily per element (galois.cpp:18-51)
+    std::vector<uint32_t *> galois_tables; // [N] entries index (elt-1)>>1, device pointers
+    void *mutex = nullptr;
+};

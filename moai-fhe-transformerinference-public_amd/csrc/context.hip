@@ -1,0 +1,502 @@
+// context.hip -- host-side precomputation and the device arena of a moai_ctx.
+//
+// Product code (not the oracle): re-provides, per prime, what the reference precomputes in
+// NTTTables::initialize (SEAL/util/ntt.cpp:241-300), Modulus::set_value (SEAL/modulus.cpp:36-77)
+// and RNSTool::initialize's inv_q_last_mod_q (SEAL/util/rns.cpp:769-775).  One table per prime,
+// shared by every level of the modulus chain.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "common.h"
+
+namespace moai {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const char *last_error()
+{
+    return g_err;
+}
+
+typedef unsigned __int128 u128;
+
+static inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q)
+{
+    return (uint64_t)(((u128)a * b) % q);
+}
+
+static uint64_t powmod(uint64_t a, uint64_t e, uint64_t q)
+{
+    uint64_t r = 1;
+    a %= q;
+    while (e)
+    {
+        if (e & 1)
+        {
+            r = mulmod(r, a, q);
+        }
+        a = mulmod(a, a, q);
+        e >>= 1;
+    }
+    return r;
+}
+
+static bool is_prime_u64(uint64_t n)
+{
+    static const uint64_t bases[] = { 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37 };
+    if (n < 2)
+    {
+        return false;
+    }
+    for (uint64_t p : bases)
+    {
+        if (n == p)
+        {
+            return true;
+        }
+        if (n % p == 0)
+        {
+            return false;
+        }
+    }
+    uint64_t d = n - 1;
+    int r = 0;
+    while (!(d & 1))
+    {
+        d >>= 1;
+        r++;
+    }
+    for (uint64_t a : bases)
+    {
+        uint64_t x = powmod(a, d, n);
+        if (x == 1 || x == n - 1)
+        {
+            continue;
+        }
+        bool comp = true;
+        for (int i = 1; i < r; i++)
+        {
+            x = mulmod(x, x, n);
+            if (x == n - 1)
+            {
+                comp = false;
+                break;
+            }
+        }
+        if (comp)
+        {
+            return false;
+        }
+    }
+    return true;
+}
+
+static inline uint32_t bitrev(uint32_t x, int bits)
+{
+    return bits ? (__builtin_bitreverse32(x) >> (32 - bits)) : 0;
+}
+
+// The smallest primitive 2N-th root of unity mod q: the value the reference's
+// try_minimal_primitive_root converges to (SEAL/util/numth.cpp:386-413).
+static bool minimal_primitive_root(uint64_t two_n, uint64_t q, uint64_t *out)
+{
+    if ((q - 1) % two_n)
+    {
+        return false;
+    }
+    uint64_t cof = (q - 1) / two_n;
+    uint64_t root = 0;
+    for (uint64_t c = 2; c < 4096 && c < q; c++)
+    {
+        uint64_t r = powmod(c, cof, q);
+        if (powmod(r, two_n >> 1, q) == q - 1)
+        {
+            root = r;
+            break;
+        }
+    }
+    if (!root)
+    {
+        return false;
+    }
+    // all primitive 2N-th roots are the odd powers of one of them
+    uint64_t sq = mulmod(root, root, q);
+    uint64_t cur = root, best = root;
+    for (uint64_t i = 0; i < two_n; i += 2)
+    {
+        if (cur < best)
+        {
+            best = cur;
+        }
+        cur = mulmod(cur, sq, q);
+    }
+    *out = best;
+    return true;
+}
+
+static inline Tw make_tw(uint64_t w, uint64_t q)
+{
+    Tw t;
+    t.w = w;
+    t.wq = (uint64_t)((((u128)w) << 64) / q);
+    return t;
+}
+
+static void build_prime(int logn, uint64_t q, uint64_t psi, Tw *fwd, Tw *inv, PrimeConst *pc)
+{
+    const size_t n = (size_t)1 << logn;
+    uint64_t psi_inv = powmod(psi, q - 2, q);
+    uint64_t p = 1, pi = 1;
+    // fwd[bitrev(i)] = psi^i ; inv[bitrev(i)] = psi^-i   (i >= 1; index 0 is never used by a stage)
+    for (size_t i = 0; i < n; i++)
+    {
+        uint32_t r = bitrev((uint32_t)i, logn);
+        fwd[r] = make_tw(p, q);
+        inv[r] = make_tw(pi, q);
+        p = mulmod(p, psi, q);
+        pi = mulmod(pi, psi_inv, q);
+    }
+    memset(pc, 0, sizeof(*pc));
+    pc->q = q;
+    pc->q2 = q << 1;
+    {
+        // floor(2^128 / q)
+        u128 hi = ((u128)1 << 64);
+        uint64_t q1 = (uint64_t)(hi / q);
+        u128 rem = hi % q;
+        uint64_t q0 = (uint64_t)((rem << 64) / q);
+        pc->cr0 = q0;
+        pc->cr1 = q1;
+    }
+    uint64_t ninv = powmod((uint64_t)n % q, q - 2, q);
+    pc->ninv = make_tw(ninv, q);
+    pc->ninv_w1 = make_tw(mulmod(ninv, n > 1 ? inv[1].w : 1, q), q);
+}
+
+} // namespace moai
+
+using namespace moai;
+
+extern "C" const char *moai_last_error(void)
+{
+    return moai::last_error();
+}
+
+extern "C" int moai_version(void)
+{
+    return 100;
+}
+
+extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int device, moai_ctx **out)
+{
+    if (!out || !primes)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    *out = nullptr;
+    if (logn < 1 || logn > 16)
+    {
+        return set_error(MOAI_EINVAL, "coeff_count_power out of range (1..16)");
+    }
+    if (k < 1 || k > MOAI_MAX_RNS)
+    {
+        return set_error(MOAI_EINVAL, "prime count out of range (1..%d)", MOAI_MAX_RNS);
+    }
+    const size_t n = (size_t)1 << logn;
+    for (size_t i = 0; i < k; i++)
+    {
+        uint64_t q = primes[i];
+        if (q >> 61 || q < 3 || (q - 1) % (2 * n) != 0 || !is_prime_u64(q))
+        {
+            return set_error(MOAI_EINVAL, "invalid modulus %llu: need a prime = 1 mod 2N below 2^61",
+                             (unsigned long long)q);
+        }
+        for (size_t j = 0; j < i; j++)
+        {
+            if (primes[j] == q)
+            {
+                return set_error(MOAI_EINVAL, "coeff_modulus is not pairwise distinct");
+            }
+        }
+    }
+    MOAI_HIP_CHECK(hipSetDevice(device));
+    moai_ctx *c = new moai_ctx();
+    c->device = device;
+    c->logn = logn;
+    c->n = n;
+    c->k = k;
+    c->primes.assign(primes, primes + k);
+    c->roots.resize(k);
+    c->pc_host.resize(k);
+    c->mutex = new std::mutex();
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+    {
+        c->num_cu = prop.multiProcessorCount;
+    }
+
+    std::vector<Tw> fwd(k * n), inv(k * n);
+    bool ok = true;
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt ? (nt > 16 ? 16 : nt) : 4;
+        std::vector<std::thread> th;
+        std::mutex mu;
+        size_t next = 0;
+        for (unsigned t = 0; t < nt; t++)
+        {
+            th.emplace_back([&]() {
+                for (;;)
+                {
+                    size_t i;
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        i = next++;
+                    }
+                    if (i >= k)
+                    {
+                        return;
+                    }
+                    uint64_t psi;
+                    if (!minimal_primitive_root(2 * n, primes[i], &psi))
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        ok = false;
+                        continue;
+                    }
+                    c->roots[i] = psi;
+                    build_prime(logn, primes[i], psi, &fwd[i * n], &inv[i * n], &c->pc_host[i]);
+                }
+            });
+        }
+        for (auto &t : th)
+        {
+            t.join();
+        }
+    }
+    if (!ok)
+    {
+        moai_ctx_destroy(c);
+        return set_error(MOAI_EINVAL, "invalid modulus: no primitive 2N-th root");
+    }
+    // inv_qlast[l*k + i] = q_l^-1 mod q_i  (for all l != i; the rescale uses l = L-1 > i, the
+    // key-switch mod-down uses l = k-1)
+    c->inv_qlast_host.assign(k * k, Tw{ 0, 0 });
+    for (size_t l = 0; l < k; l++)
+    {
+        for (size_t i = 0; i < k; i++)
+        {
+            if (i != l)
+            {
+                uint64_t qi = primes[i];
+                c->inv_qlast_host[l * k + i] = make_tw(powmod(primes[l] % qi, qi - 2, qi), qi);
+            }
+        }
+    }
+    hipError_t e;
+    if ((e = hipMalloc(&c->fwd_tw, sizeof(Tw) * k * n)) != hipSuccess ||
+        (e = hipMalloc(&c->inv_tw, sizeof(Tw) * k * n)) != hipSuccess ||
+        (e = hipMalloc(&c->pc, sizeof(PrimeConst) * k)) != hipSuccess ||
+        (e = hipMalloc(&c->inv_qlast, sizeof(Tw) * k * k)) != hipSuccess ||
+        (e = hipMemcpy(c->fwd_tw, fwd.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(c->inv_tw, inv.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(c->pc, c->pc_host.data(), sizeof(PrimeConst) * k, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(c->inv_qlast, c->inv_qlast_host.data(), sizeof(Tw) * k * k, hipMemcpyHostToDevice)) !=
+            hipSuccess)
+    {
+        moai_ctx_destroy(c);
+        return set_error(MOAI_EHIP, "context upload failed: %s", hipGetErrorString(e));
+    }
+    c->galois_tables.assign(n, nullptr);
+    *out = c;
+    return MOAI_OK;
+}
+
+extern "C" void moai_ctx_destroy(moai_ctx *c)
+{
+    if (!c)
+    {
+        return;
+    }
+    (void)hipFree(c->fwd_tw);
+    (void)hipFree(c->inv_tw);
+    (void)hipFree(c->pc);
+    (void)hipFree(c->inv_qlast);
+    (void)hipFree(c->ws);
+    for (uint32_t *t : c->galois_tables)
+    {
+        if (t)
+        {
+            (void)hipFree(t);
+        }
+    }
+    delete static_cast<std::mutex *>(c->mutex);
+    delete c;
+}
+
+extern "C" int moai_ctx_reserve(moai_ctx *c, size_t bytes)
+{
+    if (!c)
+    {
+        return set_error(MOAI_EINVAL, "null context");
+    }
+    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+    if (bytes <= c->ws_bytes)
+    {
+        return MOAI_OK;
+    }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    (void)st;
+    MOAI_HIP_CHECK(hipDeviceSynchronize());
+    if (c->ws)
+    {
+        MOAI_HIP_CHECK(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&c->ws, bytes);
+    if (e != hipSuccess)
+    {
+        return set_error(MOAI_ENOMEM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
+    }
+    c->ws_bytes = bytes;
+    return MOAI_OK;
+}
+
+extern "C" size_t moai_ctx_coeff_count(const moai_ctx *c)
+{
+    return c ? c->n : 0;
+}
+
+extern "C" size_t moai_ctx_prime_count(const moai_ctx *c)
+{
+    return c ? c->k : 0;
+}
+
+extern "C" uint64_t moai_ctx_root(const moai_ctx *c, size_t prime)
+{
+    return (c && prime < c->k) ? c->roots[prime] : 0;
+}
+
+// ---- memory / stream plumbing ---------------------------------------------------------------------
+extern "C" int moai_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e != hipSuccess)
+    {
+        return set_error(MOAI_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return MOAI_OK;
+}
+
+extern "C" int moai_free(void *dptr)
+{
+    MOAI_HIP_CHECK(hipFree(dptr));
+    return MOAI_OK;
+}
+
+extern "C" int moai_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_memset_zero(void *dst, size_t bytes, void *stream)
+{
+    MOAI_HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_stream_create(void **stream)
+{
+    hipStream_t s;
+    MOAI_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return MOAI_OK;
+}
+
+extern "C" int moai_stream_destroy(void *stream)
+{
+    MOAI_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_stream_sync(void *stream)
+{
+    MOAI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_device_info(int device, char *name, size_t cap, int *cus, size_t *hbm)
+{
+    hipDeviceProp_t prop;
+    MOAI_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (name && cap)
+    {
+        snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cus)
+    {
+        *cus = prop.multiProcessorCount;
+    }
+    if (hbm)
+    {
+        *hbm = prop.totalGlobalMem;
+    }
+    return MOAI_OK;
+}
+
+extern "C" int moai_event_create(void **ev)
+{
+    hipEvent_t e;
+    MOAI_HIP_CHECK(hipEventCreate(&e));
+    *ev = (void *)e;
+    return MOAI_OK;
+}
+
+extern "C" int moai_event_destroy(void *ev)
+{
+    MOAI_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+    return MOAI_OK;
+}
+
+extern "C" int moai_event_record(void *ev, void *stream)
+{
+    MOAI_HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return MOAI_OK;
+}
+
+extern "C" int moai_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    MOAI_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    MOAI_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MOAI_OK;
+}

@@ -1,0 +1,542 @@
+// elementwise.hip -- HBM-bound RNS polynomial arithmetic: add / sub / negate / dyadic product /
+// scalar rows / ciphertext tensor product / level drop / Galois gather.
+//
+// Reference: SEAL/util/polyarithsmallmod.cpp:18-278 and the Evaluator methods that call them
+// (cited per entry point in include/moai_hip.h).  Every kernel streams rows of N coefficients with
+// 16-byte accesses, one RNS prime per block row (blockIdx.y = polynomial row), so the per-prime
+// constants are wave-uniform scalars.
+#include <mutex>
+
+#include "launch.h"
+#include "modarith.cuh"
+
+namespace moai {
+
+struct EwArgs
+{
+    const uint64_t *a;
+    const uint64_t *b;
+    uint64_t *out;
+    const PrimeConst *pc;
+    uint32_t L;          // rows per polynomial
+    uint32_t n2;         // N / 2 (16-byte chunks per row)
+    uint32_t b_rows;     // rows of b (n_poly_b * L); row index is taken modulo this (broadcast)
+};
+
+enum EwOp
+{
+    EW_ADD,
+    EW_SUB,
+    EW_NEG,
+    EW_MUL
+};
+
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(EwArgs g)
+{
+    const uint32_t row = blockIdx.y;
+    const uint32_t prime = row % g.L;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q;
+    const uint64_t cr0 = pc->cr0, cr1 = pc->cr1;
+    const ulonglong2 *a2 = reinterpret_cast<const ulonglong2 *>(g.a) + (size_t)row * g.n2;
+    const ulonglong2 *b2 = reinterpret_cast<const ulonglong2 *>(g.b) + (size_t)(row % g.b_rows) * g.n2;
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)row * g.n2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        ulonglong2 x = a2[i];
+        ulonglong2 r;
+        if (OP == EW_NEG)
+        {
+            r.x = x.x ? q - x.x : 0;
+            r.y = x.y ? q - x.y : 0;
+        }
+        else
+        {
+            ulonglong2 y = b2[i];
+            if (OP == EW_ADD)
+            {
+                r.x = csub(x.x + y.x, q);
+                r.y = csub(x.y + y.y, q);
+            }
+            else if (OP == EW_SUB)
+            {
+                r.x = x.x >= y.x ? x.x - y.x : x.x + q - y.x;
+                r.y = x.y >= y.y ? x.y - y.y : x.y + q - y.y;
+            }
+            else
+            {
+                r.x = mulmod_barrett(x.x, y.x, q, cr0, cr1);
+                r.y = mulmod_barrett(x.y, y.y, q, cr0, cr1);
+            }
+        }
+        o2[i] = r;
+    }
+}
+
+struct ScalarArgs
+{
+    const uint64_t *a;
+    uint64_t *out;
+    const PrimeConst *pc;
+    uint32_t L;
+    uint32_t n2;
+    Tw s[MOAI_MAX_RNS]; // per row: reduced scalar (+ Shoup quotient)
+};
+
+template <bool MUL>
+__global__ __launch_bounds__(256) void scalar_rows_kernel(ScalarArgs g)
+{
+    const uint32_t row = blockIdx.y;
+    const uint32_t prime = row % g.L;
+    const uint64_t q = g.pc[prime].q;
+    const Tw s = g.s[prime];
+    const ulonglong2 *a2 = reinterpret_cast<const ulonglong2 *>(g.a) + (size_t)row * g.n2;
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)row * g.n2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        ulonglong2 x = a2[i];
+        ulonglong2 r;
+        if (MUL)
+        {
+            r.x = csub(mul_shoup_lazy(x.x, s.w, s.wq, q), q);
+            r.y = csub(mul_shoup_lazy(x.y, s.w, s.wq, q), q);
+        }
+        else
+        {
+            r.x = csub(x.x + s.w, q);
+            r.y = csub(x.y + s.w, q);
+        }
+        o2[i] = r;
+    }
+}
+
+struct CtMulArgs
+{
+    const uint64_t *x; // [batch][2][L][N]
+    const uint64_t *y; // [batch][2][L][N] (== x for the square)
+    uint64_t *out;     // [batch][3][L][N]
+    const PrimeConst *pc;
+    uint32_t L;
+    uint32_t n2;
+};
+
+// blockIdx.y = b * L + prime
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void ct_mul_kernel(CtMulArgs g)
+{
+    const uint32_t b = blockIdx.y / g.L;
+    const uint32_t prime = blockIdx.y % g.L;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const size_t rs = g.n2; // row stride in chunks
+    const ulonglong2 *x0 = reinterpret_cast<const ulonglong2 *>(g.x) + ((size_t)(b * 2 + 0) * g.L + prime) * rs;
+    const ulonglong2 *x1 = reinterpret_cast<const ulonglong2 *>(g.x) + ((size_t)(b * 2 + 1) * g.L + prime) * rs;
+    const ulonglong2 *y0 = reinterpret_cast<const ulonglong2 *>(g.y) + ((size_t)(b * 2 + 0) * g.L + prime) * rs;
+    const ulonglong2 *y1 = reinterpret_cast<const ulonglong2 *>(g.y) + ((size_t)(b * 2 + 1) * g.L + prime) * rs;
+    ulonglong2 *o0 = reinterpret_cast<ulonglong2 *>(g.out) + ((size_t)(b * 3 + 0) * g.L + prime) * rs;
+    ulonglong2 *o1 = reinterpret_cast<ulonglong2 *>(g.out) + ((size_t)(b * 3 + 1) * g.L + prime) * rs;
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(g.out) + ((size_t)(b * 3 + 2) * g.L + prime) * rs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        ulonglong2 a0 = x0[i], a1 = x1[i];
+        ulonglong2 r0, r1, r2;
+        if (SQUARE)
+        {
+            // (c0^2, 2 c0 c1, c1^2)   SEAL/evaluator.cpp:1262-1274
+            uint64_t m;
+            r0.x = mulmod_barrett(a0.x, a0.x, q, cr0, cr1);
+            r0.y = mulmod_barrett(a0.y, a0.y, q, cr0, cr1);
+            m = mulmod_barrett(a0.x, a1.x, q, cr0, cr1);
+            r1.x = csub(m + m, q);
+            m = mulmod_barrett(a0.y, a1.y, q, cr0, cr1);
+            r1.y = csub(m + m, q);
+            r2.x = mulmod_barrett(a1.x, a1.x, q, cr0, cr1);
+            r2.y = mulmod_barrett(a1.y, a1.y, q, cr0, cr1);
+        }
+        else
+        {
+            // (x0 y0, x0 y1 + x1 y0, x1 y1)   SEAL/evaluator.cpp:805-860
+            ulonglong2 b0 = y0[i], b1 = y1[i];
+            r0.x = mulmod_barrett(a0.x, b0.x, q, cr0, cr1);
+            r0.y = mulmod_barrett(a0.y, b0.y, q, cr0, cr1);
+            r1.x = csub(mulmod_barrett(a0.x, b1.x, q, cr0, cr1) + mulmod_barrett(a1.x, b0.x, q, cr0, cr1), q);
+            r1.y = csub(mulmod_barrett(a0.y, b1.y, q, cr0, cr1) + mulmod_barrett(a1.y, b0.y, q, cr0, cr1), q);
+            r2.x = mulmod_barrett(a1.x, b1.x, q, cr0, cr1);
+            r2.y = mulmod_barrett(a1.y, b1.y, q, cr0, cr1);
+        }
+        o0[i] = r0;
+        o1[i] = r1;
+        o2[i] = r2;
+    }
+}
+
+// out row (p, i<Lout) = in row (p, i): blockIdx.y = p * Lout + i
+__global__ __launch_bounds__(256) void drop_rows_kernel(const uint64_t *in, uint64_t *out, uint32_t Lin, uint32_t Lout,
+                                                        uint32_t n2)
+{
+    const uint32_t p = blockIdx.y / Lout;
+    const uint32_t i = blockIdx.y % Lout;
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(in) + ((size_t)p * Lin + i) * n2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(out) + ((size_t)p * Lout + i) * n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n2; j += gridDim.x * 256u)
+    {
+        d[j] = s[j];
+    }
+}
+
+// out[row][i] = in[row][table[i]]   (apply_galois_ntt, SEAL/util/galois.cpp:192-218)
+__global__ __launch_bounds__(256) void galois_gather_kernel(const uint64_t *in, uint64_t *out, const uint32_t *table,
+                                                            uint32_t n)
+{
+    const uint64_t *s = in + (size_t)blockIdx.y * n;
+    uint64_t *d = out + (size_t)blockIdx.y * n;
+    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 2u; i < n; i += gridDim.x * 512u)
+    {
+        uint2 t = *reinterpret_cast<const uint2 *>(table + i);
+        ulonglong2 v;
+        v.x = s[t.x];
+        v.y = s[t.y];
+        *reinterpret_cast<ulonglong2 *>(d + i) = v;
+    }
+}
+
+// table[i] = bitrev_logn(((elt * bitrev_{logn+1}(N + i)) >> 1) & (N-1))   (galois.cpp:18-51)
+__global__ void galois_table_kernel(uint32_t *table, int logn, uint32_t elt)
+{
+    const uint32_t n = 1u << logn;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        uint32_t reversed = __brev(n + i) >> (32 - (logn + 1));
+        uint64_t raw = ((uint64_t)elt * (uint64_t)reversed) >> 1;
+        uint32_t idx = (uint32_t)raw & (n - 1);
+        table[i] = logn ? (__brev(idx) >> (32 - logn)) : 0;
+    }
+}
+
+static inline dim3 row_grid(const moai_ctx *c, size_t rows, uint32_t per_thread_chunks = 1)
+{
+    uint32_t n2 = (uint32_t)(c->n >> 1);
+    uint32_t bx = (n2 + 256u * per_thread_chunks - 1) / (256u * per_thread_chunks);
+    if (bx == 0)
+    {
+        bx = 1;
+    }
+    return dim3(bx, (uint32_t)rows);
+}
+
+static int check_rows(const moai_ctx *c, size_t n_poly, size_t L)
+{
+    if (!c)
+    {
+        return set_error(MOAI_EINVAL, "null context");
+    }
+    if (L > c->k || L > MOAI_MAX_RNS)
+    {
+        return set_error(MOAI_EINVAL, "L = %zu exceeds the context's %zu primes", L, c->k);
+    }
+    if (n_poly * L > 0x7fffffffull)
+    {
+        return set_error(MOAI_EINVAL, "batch too large for one launch");
+    }
+    return MOAI_OK;
+}
+
+int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out)
+{
+    if (!(elt & 1u) || elt >= 2 * c->n)
+    {
+        return set_error(MOAI_EINVAL, "Galois element is not valid");
+    }
+    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+    size_t idx = (elt - 1) >> 1; // GaloisTool::GetIndexFromElt, SEAL/util/galois.h
+    if (!c->galois_tables[idx])
+    {
+        uint32_t *t = nullptr;
+        MOAI_HIP_CHECK(hipMalloc(&t, sizeof(uint32_t) * c->n));
+        // built on the NULL stream and completed before first use by any stream
+        hipLaunchKernelGGL(galois_table_kernel, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, 0, t, c->logn, elt);
+        MOAI_LAUNCH_CHECK();
+        MOAI_HIP_CHECK(hipStreamSynchronize(0));
+        c->galois_tables[idx] = t;
+    }
+    (void)s;
+    *out = c->galois_tables[idx];
+    return MOAI_OK;
+}
+
+int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out)
+{
+    (void)s;
+    if (bytes > c->ws_bytes)
+    {
+        // grow with 25% headroom; this synchronises the device and must not happen under capture
+        int rc = moai_ctx_reserve(c, bytes + bytes / 4);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    *out = c->ws;
+    return MOAI_OK;
+}
+
+template <int OP>
+static int ew_launch(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t n_poly_b,
+                     size_t L, void *stream)
+{
+    int rc = check_rows(c, n_poly, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (n_poly == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!a || !out || (OP != EW_NEG && !b))
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    EwArgs g;
+    g.a = a;
+    g.b = b ? b : a;
+    g.out = out;
+    g.pc = c->pc;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    g.b_rows = (uint32_t)(n_poly_b * L);
+    hipLaunchKernelGGL(ew_kernel<OP>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+} // namespace moai
+
+using namespace moai;
+
+extern "C" int moai_add(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
+                        void *stream)
+{
+    return ew_launch<EW_ADD>(c, a, b, out, n_poly, n_poly, L, stream);
+}
+
+extern "C" int moai_sub(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
+                        void *stream)
+{
+    return ew_launch<EW_SUB>(c, a, b, out, n_poly, n_poly, L, stream);
+}
+
+extern "C" int moai_negate(moai_ctx *c, const uint64_t *a, uint64_t *out, size_t n_poly, size_t L, void *stream)
+{
+    return ew_launch<EW_NEG>(c, a, nullptr, out, n_poly, n_poly, L, stream);
+}
+
+extern "C" int moai_dyadic_mul(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly,
+                               size_t n_poly_b, size_t L, void *stream)
+{
+    if (n_poly_b != n_poly && n_poly_b != 1)
+    {
+        return set_error(MOAI_EINVAL, "n_poly_b must be n_poly or 1");
+    }
+    return ew_launch<EW_MUL>(c, a, b, out, n_poly, n_poly_b, L, stream);
+}
+
+static int scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out, size_t n_poly, size_t L,
+                       void *stream, bool mul)
+{
+    int rc = check_rows(c, n_poly, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (n_poly == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!a || !out || !scalars)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    ScalarArgs g;
+    g.a = a;
+    g.out = out;
+    g.pc = c->pc;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    for (size_t r = 0; r < L; r++)
+    {
+        uint64_t q = c->primes[r];
+        uint64_t s = scalars[r] % q; // barrett_reduce_64 in polyarithsmallmod.h:209-217
+        g.s[r].w = s;
+        g.s[r].wq = (uint64_t)((((unsigned __int128)s) << 64) / q);
+    }
+    if (mul)
+    {
+        hipLaunchKernelGGL(scalar_rows_kernel<true>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    else
+    {
+        hipLaunchKernelGGL(scalar_rows_kernel<false>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" int moai_mul_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
+                                    size_t n_poly, size_t L, void *stream)
+{
+    return scalar_rows(c, a, scalars, out, n_poly, L, stream, true);
+}
+
+extern "C" int moai_add_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
+                                    size_t n_poly, size_t L, void *stream)
+{
+    return scalar_rows(c, a, scalars, out, n_poly, L, stream, false);
+}
+
+static int ct_mul(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t L, size_t batch, void *stream,
+                  bool square)
+{
+    int rc = check_rows(c, batch * 3, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!x || !y || !out)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    if (out == x || out == y)
+    {
+        return set_error(MOAI_EINVAL, "out must not alias an input");
+    }
+    CtMulArgs g;
+    g.x = x;
+    g.y = y;
+    g.out = out;
+    g.pc = c->pc;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    if (square)
+    {
+        hipLaunchKernelGGL(ct_mul_kernel<true>, row_grid(c, batch * L), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    else
+    {
+        hipLaunchKernelGGL(ct_mul_kernel<false>, row_grid(c, batch * L), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" int moai_ct_multiply(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t L,
+                                size_t batch, void *stream)
+{
+    return ct_mul(c, x, y, out, L, batch, stream, false);
+}
+
+extern "C" int moai_ct_square(moai_ctx *c, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream)
+{
+    return ct_mul(c, x, x, out, L, batch, stream, true);
+}
+
+extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,
+                             size_t batch, void *stream)
+{
+    int rc = check_rows(c, batch * size, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (drop >= L)
+    {
+        // "end of modulus switching chain reached", SEAL/evaluator.cpp:1500-1503
+        return set_error(MOAI_EINVAL, "end of modulus switching chain reached");
+    }
+    if (batch * size == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!in || !out)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    if (in == out && batch * size > 1 && drop > 0)
+    {
+        return set_error(MOAI_EINVAL, "out must not alias in");
+    }
+    if (in == out)
+    {
+        return MOAI_OK; // a single polynomial keeps its leading rows in place
+    }
+    const size_t Lout = L - drop;
+    hipLaunchKernelGGL(drop_rows_kernel, row_grid(c, batch * size * Lout), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (uint32_t)L, (uint32_t)Lout, (uint32_t)(c->n >> 1));
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" int moai_galois_permute(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t n_poly, size_t L,
+                                   uint32_t galois_elt, void *stream)
+{
+    int rc = check_rows(c, n_poly, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (in == out)
+    {
+        return set_error(MOAI_EINVAL, "result cannot point to the same value as operand");
+    }
+    const uint32_t *table;
+    rc = galois_table(c, galois_elt, (hipStream_t)stream, &table);
+    if (rc)
+    {
+        return rc;
+    }
+    if (n_poly * L == 0)
+    {
+        return MOAI_OK;
+    }
+    uint32_t bx = (uint32_t)((c->n + 511) / 512);
+    hipLaunchKernelGGL(galois_gather_kernel, dim3(bx, (uint32_t)(n_poly * L)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, table, (uint32_t)c->n);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" uint32_t moai_galois_elt_from_step(const moai_ctx *c, int step)
+{
+    // GaloisTool::get_elt_from_step, SEAL/util/galois.cpp:53-95, generator 5 (galois.h:169)
+    if (!c)
+    {
+        set_error(MOAI_EINVAL, "null context");
+        return 0;
+    }
+    const uint32_t n = (uint32_t)c->n;
+    const uint64_t m = (uint64_t)n * 2;
+    if (step == 0)
+    {
+        return (uint32_t)(m - 1);
+    }
+    bool sign = step < 0;
+    uint32_t pos = (uint32_t)(sign ? -(int64_t)step : (int64_t)step);
+    if (pos >= (n >> 1))
+    {
+        set_error(MOAI_EINVAL, "step count too large");
+        return 0;
+    }
+    uint32_t steps = sign ? (n >> 1) - pos : pos;
+    uint64_t e = 1;
+    while (steps--)
+    {
+        e = (e * 5) & (m - 1);
+    }
+    return (uint32_t)e;
+}

@@ -1,0 +1,581 @@
+// keyswitch.hip -- rescale, key switching (relinearize / apply_galois) and modraise.
+//
+// Reference: RNSTool::divide_and_round_q_last_ntt_inplace (SEAL/util/rns.cpp:830-901),
+// Evaluator::switch_key_inplace (SEAL/evaluator.cpp:2724-3020), relinearize_internal (:1345-1400),
+// apply_galois_inplace (:2563-2665), Bootstrapper::modraise_inplace
+// (include/source/bootstrapping/Bootstrapper.cpp:2938-2992).
+//
+// Structure on the device (all batched over the leading ciphertext index):
+//   rescale:     last = INTT(c_last) -> u_i = [last + q_last/2]_{q_last} mod q_i + fix_i -> NTT_{q_i}(u_i)
+//                -> out_i = (c_i - u_i) * q_last^-1
+//   switch_key:  t = INTT(target); for each output modulus I in {q_0..q_{L-1}, p}:
+//                    ops_J = NTT_{q_I}(t_J mod q_I) for every digit J (for I == J this reproduces
+//                    target_J exactly, so no special case is needed),
+//                    acc_{K,I} = sum_J ops_J (*) key[J][K][I]   (128-bit accumulate, one Barrett);
+//                then the same "divide by the last modulus and round" step with p as the last
+//                modulus, accumulated into the ciphertext.
+// The loop over I is outermost so that the 2*L key rows of modulus I are read once per batch.
+#include <mutex>
+
+#include "launch.h"
+#include "modarith.cuh"
+
+namespace moai {
+
+// out row y (group = y / rows_per_group, w = y % rows_per_group) = in row group * in_stride + in_off + w;
+// with zero_from >= 0, rows whose w >= zero_from are written as zero instead
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint64_t *in, uint64_t *out, uint32_t rows_per_group,
+                                                        uint32_t in_stride, uint32_t in_off, uint32_t zero_from,
+                                                        uint32_t n2)
+{
+    const uint32_t grp = blockIdx.y / rows_per_group;
+    const uint32_t w = blockIdx.y % rows_per_group;
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(in) + ((size_t)grp * in_stride + in_off + w) * n2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(out) + (size_t)blockIdx.y * n2;
+    const bool zero = w >= zero_from;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 v;
+        v.x = 0;
+        v.y = 0;
+        d[j] = zero ? v : s[j];
+    }
+}
+
+static const uint32_t NO_ZERO = 0xffffffffu;
+
+struct ExpandLastArgs
+{
+    const uint64_t *last;  // [P][N], canonical under prime_last
+    uint64_t *u;           // [P][Lout][N]
+    const PrimeConst *pc;
+    uint32_t prime_last;
+    uint32_t Lout;
+    uint32_t n2;
+};
+
+// u[p][i] = ([last + q_last/2] mod q_last) mod q_i + (q_i - (q_last/2 mod q_i))     in [0, 2 q_i)
+// (rns.cpp:858-878 / evaluator.cpp:2964-2992)
+__global__ __launch_bounds__(256) void expand_last_kernel(ExpandLastArgs g)
+{
+    const uint32_t p = blockIdx.y / g.Lout;
+    const uint32_t i = blockIdx.y % g.Lout;
+    const uint64_t ql = g.pc[g.prime_last].q;
+    const uint64_t half = ql >> 1;
+    const PrimeConst *pc = g.pc + i;
+    const uint64_t q = pc->q, cr1 = pc->cr1;
+    const uint64_t fix = q - barrett64(half, q, cr1);
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(g.last) + (size_t)p * g.n2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(g.u) + (size_t)blockIdx.y * g.n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < g.n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 v = s[j];
+        ulonglong2 r;
+        r.x = barrett64(csub(v.x + half, ql), q, cr1) + fix;
+        r.y = barrett64(csub(v.y + half, ql), q, cr1) + fix;
+        d[j] = r;
+    }
+}
+
+struct FinalizeArgs
+{
+    const uint64_t *acc;   // row (p, i) at acc + (p * acc_stride + i) * N
+    const uint64_t *u;     // [P][Lout][N] canonical
+    uint64_t *out;         // [P][Lout][N]
+    const PrimeConst *pc;
+    const Tw *inv_last;    // inv_qlast + prime_last * k : q_last^-1 mod q_i
+    uint32_t acc_stride;
+    uint32_t Lout;
+    uint32_t n2;
+    int accumulate;        // out += result (key switch) instead of out = result (rescale)
+};
+
+// (acc_i - u_i) * q_last^-1 mod q_i      (rns.cpp:892-897 / evaluator.cpp:3012-3017)
+__global__ __launch_bounds__(256) void moddown_finalize_kernel(FinalizeArgs g)
+{
+    const uint32_t p = blockIdx.y / g.Lout;
+    const uint32_t i = blockIdx.y % g.Lout;
+    const uint64_t q = g.pc[i].q;
+    const Tw inv = g.inv_last[i];
+    const ulonglong2 *a = reinterpret_cast<const ulonglong2 *>(g.acc) + ((size_t)p * g.acc_stride + i) * g.n2;
+    const ulonglong2 *u = reinterpret_cast<const ulonglong2 *>(g.u) + (size_t)blockIdx.y * g.n2;
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)blockIdx.y * g.n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < g.n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 x = a[j], y = u[j], r;
+        r.x = csub(mul_shoup_lazy(x.x + q - y.x, inv.w, inv.wq, q), q);
+        r.y = csub(mul_shoup_lazy(x.y + q - y.y, inv.w, inv.wq, q), q);
+        if (g.accumulate)
+        {
+            ulonglong2 c = o[j];
+            r.x = csub(r.x + c.x, q);
+            r.y = csub(r.y + c.y, q);
+        }
+        o[j] = r;
+    }
+}
+
+// ops[b][J] = t[b][J] mod q_I   (evaluator.cpp:2844-2854); all rows under one prime
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const uint64_t *t, uint64_t *ops, const PrimeConst *pc,
+                                                          uint32_t prime, uint32_t n2)
+{
+    const uint64_t q = pc[prime].q, cr1 = pc[prime].cr1;
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(t) + (size_t)blockIdx.y * n2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(ops) + (size_t)blockIdx.y * n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 v = s[j];
+        v.x = barrett64(v.x, q, cr1);
+        v.y = barrett64(v.y, q, cr1);
+        d[j] = v;
+    }
+}
+
+struct MacArgs
+{
+    const uint64_t *ops;   // [B][L][N] NTT form under prime I
+    const uint64_t *key;   // [k-1][2][k][N]
+    uint64_t *acc;         // [B][2][L+1][N]
+    const PrimeConst *pc;
+    uint32_t L;
+    uint32_t k;
+    uint32_t prime;        // I (context prime index)
+    uint32_t slot;         // row of acc to write (I, or L for the special prime)
+    uint32_t n2;
+};
+
+__device__ __forceinline__ void mac128(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
+{
+    uint64_t pl = a * b;
+    uint64_t ph = mulhi64(a, b);
+    lo += pl;
+    hi += ph + (lo < pl ? 1 : 0);
+}
+
+// acc[b][K][slot] = sum_J ops[b][J] (*) key[J][K][prime]  mod q      (evaluator.cpp:2858-2910)
+// blockIdx.y = b
+__global__ __launch_bounds__(256) void keyswitch_mac_kernel(MacArgs g)
+{
+    const PrimeConst *pc = g.pc + g.prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const uint32_t b = blockIdx.y;
+    const size_t n2 = g.n2;
+    const ulonglong2 *ops = reinterpret_cast<const ulonglong2 *>(g.ops) + (size_t)b * g.L * n2;
+    const ulonglong2 *key = reinterpret_cast<const ulonglong2 *>(g.key);
+    ulonglong2 *acc0 = reinterpret_cast<ulonglong2 *>(g.acc) + ((size_t)(b * 2 + 0) * (g.L + 1) + g.slot) * n2;
+    ulonglong2 *acc1 = reinterpret_cast<ulonglong2 *>(g.acc) + ((size_t)(b * 2 + 1) * (g.L + 1) + g.slot) * n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < g.n2; j += gridDim.x * 256u)
+    {
+        uint64_t l0x = 0, h0x = 0, l0y = 0, h0y = 0, l1x = 0, h1x = 0, l1y = 0, h1y = 0;
+        for (uint32_t J = 0; J < g.L; ++J)
+        {
+            ulonglong2 o = ops[(size_t)J * n2 + j];
+            ulonglong2 k0 = key[((size_t)(J * 2 + 0) * g.k + g.prime) * n2 + j];
+            ulonglong2 k1 = key[((size_t)(J * 2 + 1) * g.k + g.prime) * n2 + j];
+            mac128(l0x, h0x, o.x, k0.x);
+            mac128(l0y, h0y, o.y, k0.y);
+            mac128(l1x, h1x, o.x, k1.x);
+            mac128(l1y, h1y, o.y, k1.y);
+        }
+        ulonglong2 r0, r1;
+        r0.x = barrett128(l0x, h0x, q, cr0, cr1);
+        r0.y = barrett128(l0y, h0y, q, cr0, cr1);
+        r1.x = barrett128(l1x, h1x, q, cr0, cr1);
+        r1.y = barrett128(l1y, h1y, q, cr0, cr1);
+        acc0[j] = r0;
+        acc1[j] = r1;
+    }
+}
+
+struct RaiseArgs
+{
+    const uint64_t *src;  // [P][N] coefficient form, canonical mod q0
+    uint64_t *out;        // [P][Lout][N]
+    const PrimeConst *pc;
+    uint32_t Lout;
+    uint32_t n2;
+};
+
+// Bootstrapper.cpp:2964-2988: dest = src mod q_j, plus (q_j - q0 mod q_j) when src > q0/2
+__global__ __launch_bounds__(256) void modraise_kernel(RaiseArgs g)
+{
+    const uint32_t p = blockIdx.y / g.Lout;
+    const uint32_t jrow = blockIdx.y % g.Lout;
+    const uint64_t q0 = g.pc[0].q;
+    const uint64_t q = g.pc[jrow].q, cr1 = g.pc[jrow].cr1;
+    const uint64_t minus_q0 = jrow == 0 ? 0 : q - barrett64(q0, q, cr1);
+    const uint64_t half = q0 >> 1;
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(g.src) + (size_t)p * g.n2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)blockIdx.y * g.n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < g.n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 v = s[j], r;
+        r.x = barrett64(v.x, q, cr1);
+        r.y = barrett64(v.y, q, cr1);
+        if (v.x > half)
+        {
+            r.x = csub(r.x + minus_q0, q);
+        }
+        if (v.y > half)
+        {
+            r.y = csub(r.y + minus_q0, q);
+        }
+        d[j] = r;
+    }
+}
+
+static inline dim3 rgrid(const moai_ctx *c, size_t rows)
+{
+    uint32_t n2 = (uint32_t)(c->n >> 1);
+    uint32_t bx = (n2 + 255u) / 256u;
+    return dim3(bx ? bx : 1, (uint32_t)rows);
+}
+
+static inline size_t align256(size_t x)
+{
+    return (x + 255) & ~(size_t)255;
+}
+
+// Shared tail of rescale and key switch: divide rows [0, Lout) of `acc` by the modulus `prime_last`
+// whose NTT-form row is `last_rows` ([P][N], overwritten), rounding to nearest.
+//   acc row (p, i) = acc + (p * acc_stride + i) * N ; out [P][Lout][N]
+// scratch: u [P][Lout][N]
+static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32_t acc_stride, uint64_t *u,
+                   uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, bool accumulate, hipStream_t s)
+{
+    RowMap rm;
+    uint32_t pl = prime_last;
+    int rc = make_rowmap(c, 1, &pl, &rm);
+    if (rc)
+    {
+        return rc;
+    }
+    rc = ntt_launch(c, last_rows, P, 1, rm, true, s);
+    if (rc)
+    {
+        return rc;
+    }
+    ExpandLastArgs e;
+    e.last = last_rows;
+    e.u = u;
+    e.pc = c->pc;
+    e.prime_last = prime_last;
+    e.Lout = (uint32_t)Lout;
+    e.n2 = (uint32_t)(c->n >> 1);
+    hipLaunchKernelGGL(expand_last_kernel, rgrid(c, P * Lout), dim3(256), 0, s, e);
+    MOAI_LAUNCH_CHECK();
+    rc = make_rowmap(c, Lout, nullptr, &rm);
+    if (rc)
+    {
+        return rc;
+    }
+    rc = ntt_launch(c, u, P, Lout, rm, false, s);
+    if (rc)
+    {
+        return rc;
+    }
+    FinalizeArgs f;
+    f.acc = acc;
+    f.u = u;
+    f.out = out;
+    f.pc = c->pc;
+    f.inv_last = c->inv_qlast + (size_t)prime_last * c->k;
+    f.acc_stride = acc_stride;
+    f.Lout = (uint32_t)Lout;
+    f.n2 = (uint32_t)(c->n >> 1);
+    f.accumulate = accumulate ? 1 : 0;
+    hipLaunchKernelGGL(moddown_finalize_kernel, rgrid(c, P * Lout), dim3(256), 0, s, f);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+static int check_level(const moai_ctx *c, size_t L, size_t polys)
+{
+    if (!c)
+    {
+        return set_error(MOAI_EINVAL, "null context");
+    }
+    if (L == 0 || L > c->k)
+    {
+        return set_error(MOAI_EINVAL, "L = %zu out of range for a context of %zu primes", L, c->k);
+    }
+    if (polys * (L + 1) > 0x7fffffffull)
+    {
+        return set_error(MOAI_EINVAL, "batch too large for one launch");
+    }
+    return MOAI_OK;
+}
+
+static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
+{
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    return align256(batch * L * row_bytes) + align256(2 * batch * L * row_bytes) +
+           align256(batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
+}
+
+// target row block of ciphertext b starts at target + (b * target_stride_rows + target_off_rows) * N.
+// wsp: switch_key_ws_bytes() bytes of scratch.
+static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, size_t target_stride_rows,
+                           size_t target_off_rows, const uint64_t *key, size_t L, size_t batch, void *wsp,
+                           hipStream_t s)
+{
+    const size_t n = c->n;
+    const size_t k = c->k;
+    if (k < 2)
+    {
+        return set_error(MOAI_ELOGIC, "keyswitching is not supported by the context");
+    }
+    if (L > k - 1)
+    {
+        return set_error(MOAI_EINVAL, "L exceeds the key's decomposition size");
+    }
+    const size_t row_bytes = n * sizeof(uint64_t);
+    const size_t sz_t = align256(batch * L * row_bytes);
+    const size_t sz_ops = align256(2 * batch * L * row_bytes); // also holds u [2B][L][N]
+    const size_t sz_acc = align256(batch * 2 * (L + 1) * row_bytes);
+    uint64_t *t = static_cast<uint64_t *>(wsp);
+    uint64_t *ops = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_t);
+    uint64_t *acc = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_t + sz_ops);
+    uint64_t *last = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_t + sz_ops + sz_acc);
+    const uint32_t n2 = (uint32_t)(n >> 1);
+
+    // 1. t = INTT(target)      (evaluator.cpp:2804-2812)
+    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, target, t, (uint32_t)L,
+                       (uint32_t)target_stride_rows, (uint32_t)target_off_rows, NO_ZERO, n2);
+    MOAI_LAUNCH_CHECK();
+    RowMap rm;
+    int rc = make_rowmap(c, L, nullptr, &rm);
+    if (rc)
+    {
+        return rc;
+    }
+    rc = ntt_launch(c, t, batch, L, rm, true, s);
+    if (rc)
+    {
+        return rc;
+    }
+    // 2. inner products per output modulus    (evaluator.cpp:2817-2911)
+    for (size_t Iidx = 0; Iidx <= L; ++Iidx)
+    {
+        const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+        hipLaunchKernelGGL(reduce_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, t, ops, c->pc, prime, n2);
+        MOAI_LAUNCH_CHECK();
+        for (size_t r = 0; r < L; ++r)
+        {
+            rm.idx[r] = (uint16_t)prime;
+        }
+        rc = ntt_launch(c, ops, batch, L, rm, false, s);
+        if (rc)
+        {
+            return rc;
+        }
+        MacArgs m;
+        m.ops = ops;
+        m.key = key;
+        m.acc = acc;
+        m.pc = c->pc;
+        m.L = (uint32_t)L;
+        m.k = (uint32_t)k;
+        m.prime = prime;
+        m.slot = (uint32_t)Iidx;
+        m.n2 = n2;
+        hipLaunchKernelGGL(keyswitch_mac_kernel, rgrid(c, batch), dim3(256), 0, s, m);
+        MOAI_LAUNCH_CHECK();
+    }
+    // 3. mod-down by the special prime, accumulated into ct   (evaluator.cpp:2913-3018)
+    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc, last, 1u, (uint32_t)(L + 1),
+                       (uint32_t)L, NO_ZERO, n2);
+    MOAI_LAUNCH_CHECK();
+    return moddown(c, last, acc, (uint32_t)(L + 1), ops, ct, batch * 2, L, (uint32_t)(k - 1), true, s);
+}
+
+} // namespace moai
+
+using namespace moai;
+
+extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
+                            void *stream)
+{
+    const size_t P = batch * size;
+    int rc = check_level(c, L, P);
+    if (rc)
+    {
+        return rc;
+    }
+    if (L < 2)
+    {
+        // SEAL/evaluator.cpp:1693-1696
+        return set_error(MOAI_EINVAL, "end of modulus switching chain reached");
+    }
+    if (P == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!in || !out || in == out)
+    {
+        return set_error(MOAI_EINVAL, "bad in/out pointers");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    const size_t sz_last = align256(P * row_bytes);
+    const size_t sz_u = align256(P * (L - 1) * row_bytes);
+    void *wsp;
+    rc = workspace(c, sz_last + sz_u, s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    uint64_t *last = static_cast<uint64_t *>(wsp);
+    uint64_t *u = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_last);
+    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1),
+                       NO_ZERO, (uint32_t)(c->n >> 1));
+    MOAI_LAUNCH_CHECK();
+    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), false, s);
+}
+
+extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,
+                               size_t batch, void *stream)
+{
+    int rc = check_level(c, L, batch * 2);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!ct || !target || !key)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    void *wsp;
+    rc = workspace(c, switch_key_ws_bytes(c, L, batch), (hipStream_t)stream, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    return switch_key_impl(c, ct, target, L, 0, key, L, batch, wsp, (hipStream_t)stream);
+}
+
+extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t *relin_key, uint64_t *out, size_t L,
+                                size_t batch, void *stream)
+{
+    int rc = check_level(c, L, batch * 3);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!ct3 || !relin_key || !out || out == ct3)
+    {
+        return set_error(MOAI_EINVAL, "bad pointers");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    void *wsp;
+    rc = workspace(c, switch_key_ws_bytes(c, L, batch), s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    // out = (c0, c1); out += switch_key(c2, relin_keys[0])      (evaluator.cpp:1383-1392)
+    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2 * L), dim3(256), 0, s, ct3, out, (uint32_t)(2 * L),
+                       (uint32_t)(3 * L), 0u, NO_ZERO, (uint32_t)(c->n >> 1));
+    MOAI_LAUNCH_CHECK();
+    return switch_key_impl(c, out, ct3, 3 * L, 2 * L, relin_key, L, batch, wsp, s);
+}
+
+extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t galois_elt, const uint64_t *galois_key,
+                                 size_t batch, void *stream)
+{
+    int rc = check_level(c, L, batch * 2);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!ct || !galois_key)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    const size_t sz_tmp = align256(batch * 2 * L * row_bytes);
+    void *wsp;
+    rc = workspace(c, sz_tmp + switch_key_ws_bytes(c, L, batch), s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    uint64_t *tmp = static_cast<uint64_t *>(wsp);
+    void *ks_ws = static_cast<char *>(wsp) + sz_tmp;
+    // tmp = galois(ct) for both polynomials; ct = (tmp0, 0); ct += switch_key(tmp1)  (evaluator.cpp:2631-2654)
+    rc = moai_galois_permute(c, ct, tmp, batch * 2, L, galois_elt, stream);
+    if (rc)
+    {
+        return rc;
+    }
+    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2 * L), dim3(256), 0, s, tmp, ct, (uint32_t)(2 * L),
+                       (uint32_t)(2 * L), 0u, (uint32_t)L, (uint32_t)(c->n >> 1));
+    MOAI_LAUNCH_CHECK();
+    return switch_key_impl(c, ct, tmp, 2 * L, L, galois_key, L, batch, ks_ws, s);
+}
+
+extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream)
+{
+    const size_t P = batch * 2;
+    int rc = check_level(c, L_out, P);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!in || !out || in == out)
+    {
+        return set_error(MOAI_EINVAL, "bad pointers");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    void *wsp;
+    rc = workspace(c, align256(P * row_bytes), s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    uint64_t *src = static_cast<uint64_t *>(wsp);
+    MOAI_HIP_CHECK(hipMemcpyAsync(src, in, P * row_bytes, hipMemcpyDeviceToDevice, s));
+    RowMap rm;
+    rc = make_rowmap(c, 1, nullptr, &rm);
+    if (rc)
+    {
+        return rc;
+    }
+    rc = ntt_launch(c, src, P, 1, rm, true, s);
+    if (rc)
+    {
+        return rc;
+    }
+    RaiseArgs g;
+    g.src = src;
+    g.out = out;
+    g.pc = c->pc;
+    g.Lout = (uint32_t)L_out;
+    g.n2 = (uint32_t)(c->n >> 1);
+    hipLaunchKernelGGL(modraise_kernel, rgrid(c, P * L_out), dim3(256), 0, s, g);
+    MOAI_LAUNCH_CHECK();
+    rc = make_rowmap(c, L_out, nullptr, &rm);
+    if (rc)
+    {
+        return rc;
+    }
+    return ntt_launch(c, out, P, L_out, rm, false, s);
+}

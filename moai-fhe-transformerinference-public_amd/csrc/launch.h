@@ -1,0 +1,15 @@
+// launch.h -- host-side entry points shared between the translation units of the library.
+#pragma once
+#include "common.h"
+
+namespace moai {
+
+int make_rowmap(const moai_ctx *c, size_t L, const uint32_t *prime_index, RowMap *out);
+int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse,
+               hipStream_t s);
+// returns the context workspace grown to at least `bytes` (grows only outside stream capture)
+int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out);
+// device pointer to the Galois permutation table of `elt` (built on first use)
+int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out);
+
+} // namespace moai

@@ -1,0 +1,173 @@
+// ntt.hip -- launchers of the negacyclic NTT kernels (C ABI: moai_ntt_forward / moai_ntt_inverse).
+#include <cstdlib>
+
+#include "ntt_kernels.cuh"
+#include "launch.h"
+
+namespace moai {
+
+static bool naive_requested()
+{
+    static int v = -1;
+    if (v < 0)
+    {
+        const char *e = getenv("MOAI_NTT_NAIVE");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+template <int LOGN>
+static void launch_fwd(const NttArgs &base, hipStream_t s)
+{
+    NttArgs a = base;
+    constexpr uint32_t tpr_strided = 1u << (LOGN - 12);
+    a.total_work = a.n_poly * a.L * tpr_strided;
+    hipLaunchKernelGGL(ntt_fwd_strided<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ntt_fwd_contig<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
+}
+
+template <int LOGN>
+static void launch_inv(const NttArgs &base, hipStream_t s)
+{
+    NttArgs a = base;
+    constexpr uint32_t tpr = 1u << (LOGN - 12);
+    a.total_work = a.n_poly * a.L * tpr;
+    hipLaunchKernelGGL(ntt_inv_contig<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ntt_inv_strided<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
+}
+
+// data [n_poly][L][N]; rows maps row -> prime.  Returns a MOAI_* code.
+int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse, hipStream_t s)
+{
+    if (n_poly == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (n_poly * L * (c->n >> (c->logn >= 12 ? 12 : 0)) > 0x7fffffffull || n_poly > 0xffffffffull)
+    {
+        return set_error(MOAI_EINVAL, "batch too large for one launch");
+    }
+    NttArgs a;
+    a.data = data;
+    a.tw = inverse ? c->inv_tw : c->fwd_tw;
+    a.pc = c->pc;
+    a.rows = rows;
+    a.L = (uint32_t)L;
+    a.n_poly = (uint32_t)n_poly;
+    a.total_work = 0;
+    const int logn = c->logn;
+    if (naive_requested() && logn >= 1)
+    {
+        uint32_t bx = (uint32_t)(((c->n >> 1) + 255) / 256);
+        dim3 grid(bx, (uint32_t)(n_poly * L));
+        if (!inverse)
+        {
+            for (int st = 0; st < logn; ++st)
+            {
+                hipLaunchKernelGGL(ntt_stage_global<false>, grid, dim3(256), 0, s, a, logn, st, st == logn - 1);
+            }
+        }
+        else
+        {
+            for (int st = logn - 1; st >= 0; --st)
+            {
+                hipLaunchKernelGGL(ntt_stage_global<true>, grid, dim3(256), 0, s, a, logn, st, st == 0);
+            }
+        }
+        MOAI_LAUNCH_CHECK();
+        return MOAI_OK;
+    }
+    if (logn <= 11)
+    {
+        dim3 grid((uint32_t)(n_poly * L));
+        if (inverse)
+        {
+            hipLaunchKernelGGL(ntt_small<true>, grid, dim3(256), 0, s, a, logn);
+        }
+        else
+        {
+            hipLaunchKernelGGL(ntt_small<false>, grid, dim3(256), 0, s, a, logn);
+        }
+        MOAI_LAUNCH_CHECK();
+        return MOAI_OK;
+    }
+#define MOAI_NTT_CASE(LG)               \
+    case LG:                            \
+        if (inverse)                    \
+        {                               \
+            launch_inv<LG>(a, s);       \
+        }                               \
+        else                            \
+        {                               \
+            launch_fwd<LG>(a, s);       \
+        }                               \
+        break;
+    switch (logn)
+    {
+        MOAI_NTT_CASE(12)
+        MOAI_NTT_CASE(13)
+        MOAI_NTT_CASE(14)
+        MOAI_NTT_CASE(15)
+        MOAI_NTT_CASE(16)
+    default:
+        return set_error(MOAI_ELOGIC, "unsupported poly_modulus_degree 2^%d", logn);
+    }
+#undef MOAI_NTT_CASE
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+int make_rowmap(const moai_ctx *c, size_t L, const uint32_t *prime_index, RowMap *out)
+{
+    if (L > MOAI_MAX_RNS)
+    {
+        return set_error(MOAI_EINVAL, "L = %zu exceeds MOAI_MAX_RNS", L);
+    }
+    for (size_t r = 0; r < L; r++)
+    {
+        uint32_t p = prime_index ? prime_index[r] : (uint32_t)r;
+        if (p >= c->k)
+        {
+            return set_error(MOAI_ERANGE, "prime index %u out of range (k = %zu)", p, c->k);
+        }
+        out->idx[r] = (uint16_t)p;
+    }
+    for (size_t r = L; r < MOAI_MAX_RNS; r++)
+    {
+        out->idx[r] = 0;
+    }
+    return MOAI_OK;
+}
+
+} // namespace moai
+
+using namespace moai;
+
+static int ntt_entry(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index, void *stream,
+                     bool inverse)
+{
+    if (!c || (!data && n_poly * L))
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    RowMap rows;
+    int rc = make_rowmap(c, L, prime_index, &rows);
+    if (rc)
+    {
+        return rc;
+    }
+    return ntt_launch(c, data, n_poly, L, rows, inverse, (hipStream_t)stream);
+}
+
+extern "C" int moai_ntt_forward(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
+                                void *stream)
+{
+    return ntt_entry(c, data, n_poly, L, prime_index, stream, false);
+}
+
+extern "C" int moai_ntt_inverse(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
+                                void *stream)
+{
+    return ntt_entry(c, data, n_poly, L, prime_index, stream, true);
+}

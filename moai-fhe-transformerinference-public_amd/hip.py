@@ -1,0 +1,276 @@
+"""ctypes binding of libmoai_hip.so -- the C ABI declared in include/moai_hip.h.
+
+This is plumbing, not product logic: every call goes straight to the HIP library.  Residue data is
+numpy uint64 on the host and raw device pointers on the GPU, in the reference's layout
+[poly][rns prime][coefficient] (SEAL/ciphertext.h:337-349).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmoai_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+vp = C.c_void_p
+sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/moai_hip.h declares
+SYMBOLS = {
+    "moai_last_error": (C.c_char_p, []),
+    "moai_version": (C.c_int, []),
+    "moai_ctx_create": (C.c_int, [C.c_int, u64p, sz, C.c_int, C.POINTER(vp)]),
+    "moai_ctx_destroy": (None, [vp]),
+    "moai_ctx_reserve": (C.c_int, [vp, sz]),
+    "moai_ctx_coeff_count": (sz, [vp]),
+    "moai_ctx_prime_count": (sz, [vp]),
+    "moai_ctx_root": (C.c_uint64, [vp, sz]),
+    "moai_malloc": (C.c_int, [C.POINTER(vp), sz]),
+    "moai_free": (C.c_int, [vp]),
+    "moai_memcpy_h2d": (C.c_int, [vp, vp, sz, vp]),
+    "moai_memcpy_d2h": (C.c_int, [vp, vp, sz, vp]),
+    "moai_memcpy_d2d": (C.c_int, [vp, vp, sz, vp]),
+    "moai_memset_zero": (C.c_int, [vp, sz, vp]),
+    "moai_stream_create": (C.c_int, [C.POINTER(vp)]),
+    "moai_stream_destroy": (C.c_int, [vp]),
+    "moai_stream_sync": (C.c_int, [vp]),
+    "moai_ntt_forward": (C.c_int, [vp, vp, sz, sz, u32p, vp]),
+    "moai_ntt_inverse": (C.c_int, [vp, vp, sz, sz, u32p, vp]),
+    "moai_add": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
+    "moai_sub": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
+    "moai_negate": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_dyadic_mul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, vp]),
+    "moai_mul_scalar_rows": (C.c_int, [vp, vp, u64p, vp, sz, sz, vp]),
+    "moai_add_scalar_rows": (C.c_int, [vp, vp, u64p, vp, sz, sz, vp]),
+    "moai_ct_multiply": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
+    "moai_ct_square": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
+    "moai_mod_drop": (C.c_int, [vp, vp, vp, sz, sz, sz, sz, vp]),
+    "moai_galois_permute": (C.c_int, [vp, vp, vp, sz, sz, C.c_uint32, vp]),
+    "moai_galois_elt_from_step": (C.c_uint32, [vp, C.c_int]),
+    "moai_switch_key": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
+    "moai_relinearize": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
+    "moai_apply_galois": (C.c_int, [vp, vp, sz, C.c_uint32, vp, sz, vp]),
+    "moai_modraise": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
+    "moai_event_create": (C.c_int, [C.POINTER(vp)]),
+    "moai_event_destroy": (C.c_int, [vp]),
+    "moai_event_record": (C.c_int, [vp, vp]),
+    "moai_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+}
+
+
+class MoaiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("moai_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    """Load libmoai_hip.so.  Raises (never falls back) when the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError(
+                "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % _SO
+            )
+        L = C.CDLL(_SO)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MoaiError(rc, lib().moai_last_error().decode())
+
+
+class DeviceBuffer:
+    """A block of device memory holding uint64 residues (moai_malloc / moai_free)."""
+
+    def __init__(self, n_words):
+        self.n_words = int(n_words)
+        p = vp()
+        _check(lib().moai_malloc(C.byref(p), self.n_words * 8))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a, stream=None):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = cls(a.size)
+        b.upload(a, stream)
+        return b
+
+    def upload(self, a, stream=None):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        assert a.size <= self.n_words
+        _check(lib().moai_memcpy_h2d(self.ptr, a.ctypes.data, a.size * 8, stream))
+        _check(lib().moai_stream_sync(stream))
+
+    def to_numpy(self, shape=None, stream=None, words=None):
+        words = self.n_words if words is None else words
+        out = np.empty(words, dtype=np.uint64)
+        _check(lib().moai_stream_sync(stream))
+        _check(lib().moai_memcpy_d2h(out.ctypes.data, self.ptr, words * 8, stream))
+        _check(lib().moai_stream_sync(stream))
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            lib().moai_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return int(x)  # raw device pointer (e.g. torch.Tensor.data_ptr())
+
+
+class Context:
+    """moai_ctx: per-prime NTT tables and constants on the device, shared by all levels."""
+
+    def __init__(self, coeff_count_power, primes, device=0):
+        self.logn = int(coeff_count_power)
+        self.n = 1 << self.logn
+        self.primes = [int(p) for p in primes]
+        self.k = len(self.primes)
+        arr = (C.c_uint64 * self.k)(*self.primes)
+        h = vp()
+        _check(lib().moai_ctx_create(self.logn, arr, self.k, device, C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().moai_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, nbytes):
+        _check(lib().moai_ctx_reserve(self.h, int(nbytes)))
+
+    def root(self, i):
+        return int(lib().moai_ctx_root(self.h, i))
+
+    @staticmethod
+    def _pidx(prime_index):
+        if prime_index is None:
+            return None
+        return (C.c_uint32 * len(prime_index))(*[int(x) for x in prime_index])
+
+    # --- raw-pointer API (device buffers) -----------------------------------------------------------
+    def ntt_forward(self, data, n_poly, L, prime_index=None, stream=None):
+        _check(lib().moai_ntt_forward(self.h, _ptr(data), n_poly, L, self._pidx(prime_index), stream))
+
+    def ntt_inverse(self, data, n_poly, L, prime_index=None, stream=None):
+        _check(lib().moai_ntt_inverse(self.h, _ptr(data), n_poly, L, self._pidx(prime_index), stream))
+
+    def add(self, a, b, out, n_poly, L, stream=None):
+        _check(lib().moai_add(self.h, _ptr(a), _ptr(b), _ptr(out), n_poly, L, stream))
+
+    def sub(self, a, b, out, n_poly, L, stream=None):
+        _check(lib().moai_sub(self.h, _ptr(a), _ptr(b), _ptr(out), n_poly, L, stream))
+
+    def negate(self, a, out, n_poly, L, stream=None):
+        _check(lib().moai_negate(self.h, _ptr(a), _ptr(out), n_poly, L, stream))
+
+    def dyadic_mul(self, a, b, out, n_poly, n_poly_b, L, stream=None):
+        _check(lib().moai_dyadic_mul(self.h, _ptr(a), _ptr(b), _ptr(out), n_poly, n_poly_b, L, stream))
+
+    def mul_scalar_rows(self, a, scalars, out, n_poly, L, stream=None):
+        s = (C.c_uint64 * L)(*[int(x) for x in scalars])
+        _check(lib().moai_mul_scalar_rows(self.h, _ptr(a), s, _ptr(out), n_poly, L, stream))
+
+    def add_scalar_rows(self, a, scalars, out, n_poly, L, stream=None):
+        s = (C.c_uint64 * L)(*[int(x) for x in scalars])
+        _check(lib().moai_add_scalar_rows(self.h, _ptr(a), s, _ptr(out), n_poly, L, stream))
+
+    def ct_multiply(self, x, y, out, L, batch, stream=None):
+        _check(lib().moai_ct_multiply(self.h, _ptr(x), _ptr(y), _ptr(out), L, batch, stream))
+
+    def ct_square(self, x, out, L, batch, stream=None):
+        _check(lib().moai_ct_square(self.h, _ptr(x), _ptr(out), L, batch, stream))
+
+    def rescale(self, src, out, size, L, batch, stream=None):
+        _check(lib().moai_rescale(self.h, _ptr(src), _ptr(out), size, L, batch, stream))
+
+    def mod_drop(self, src, out, size, L, drop, batch, stream=None):
+        _check(lib().moai_mod_drop(self.h, _ptr(src), _ptr(out), size, L, drop, batch, stream))
+
+    def galois_permute(self, src, out, n_poly, L, elt, stream=None):
+        _check(lib().moai_galois_permute(self.h, _ptr(src), _ptr(out), n_poly, L, int(elt), stream))
+
+    def galois_elt_from_step(self, step):
+        e = lib().moai_galois_elt_from_step(self.h, int(step))
+        if e == 0:
+            raise MoaiError(-1, lib().moai_last_error().decode())
+        return int(e)
+
+    def switch_key(self, ct, target, key, L, batch, stream=None):
+        _check(lib().moai_switch_key(self.h, _ptr(ct), _ptr(target), _ptr(key), L, batch, stream))
+
+    def relinearize(self, ct3, key, out, L, batch, stream=None):
+        _check(lib().moai_relinearize(self.h, _ptr(ct3), _ptr(key), _ptr(out), L, batch, stream))
+
+    def apply_galois(self, ct, L, elt, key, batch, stream=None):
+        _check(lib().moai_apply_galois(self.h, _ptr(ct), L, int(elt), _ptr(key), batch, stream))
+
+    def modraise(self, src, out, L_out, batch, stream=None):
+        _check(lib().moai_modraise(self.h, _ptr(src), _ptr(out), L_out, batch, stream))
+
+    def sync(self, stream=None):
+        _check(lib().moai_stream_sync(stream))
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    hbm = sz(0)
+    _check(lib().moai_device_info(device, name, 256, C.byref(cus), C.byref(hbm)))
+    return name.value.decode(), cus.value, hbm.value
+
+
+class Event:
+    def __init__(self):
+        p = vp()
+        _check(lib().moai_event_create(C.byref(p)))
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        _check(lib().moai_event_record(self.ptr, stream))
+
+    def elapsed_ms_since(self, start):
+        ms = C.c_float(0)
+        _check(lib().moai_event_elapsed_ms(start.ptr, self.ptr, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().moai_event_destroy(self.ptr)
+        except Exception:
+            pass

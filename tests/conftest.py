@@ -18,3 +18,10 @@ def kats():
 
     with open(os.path.join(ROOT, "tests", "golden", "seal_kats.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def moai():
+    import __graft_entry__ as g
+
+    return g.load_package()

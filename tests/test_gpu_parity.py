@@ -1,0 +1,318 @@
+"""GPU parity: every C-ABI entry point against the CPU oracle on the same seeded inputs, bit-exact
+(integer path: no tolerance).  Runs on the MI355X box only (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MOAI_BITS = [51] + [46] * 20 + [51] * 14 + [58]  # include/test/test_full_scheme.hpp:356-378
+
+
+def up(m, a):
+    return m.DeviceBuffer.from_numpy(a)
+
+
+@pytest.fixture(scope="module")
+def env12(moai):
+    logn = 12
+    primes = O.coeff_modulus_create(1 << logn, [51, 46, 46, 51, 58])
+    return logn, primes, O.Context(logn, primes), moai.Context(logn, primes)
+
+
+@pytest.mark.parametrize("logn,bits", [
+    (1, [60]), (2, [50, 30]), (3, [60, 20]), (5, [46, 51]), (8, [58, 61]), (10, [60, 40, 61]), (11, [46, 51, 58]),
+    (12, [61, 46, 20]), (13, [60, 40, 60]), (14, [51, 58, 30]), (15, [60, 40, 40, 60]), (16, [60, 51, 46, 58, 61]),
+])
+def test_ntt_matches_oracle(moai, logn, bits):
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    for i in range(len(primes)):
+        assert ctx.root(i) == int(octx_root(logn, primes[i]))
+    rng = np.random.default_rng(logn)
+    L, npoly = len(primes), 3
+    x = O.uniform_rns(rng, primes, (npoly,), n)
+    # edge values: 0, q-1 rows
+    x[0, :, 0] = 0
+    for i, q in enumerate(primes):
+        x[1, i, :4 if n >= 4 else n] = q - 1
+    d = up(moai, x)
+    ctx.ntt_forward(d, npoly, L)
+    got = d.to_numpy(x.shape)
+    assert (got == octx.ntt(x, L)).all()
+    ctx.ntt_inverse(d, npoly, L)
+    assert (d.to_numpy(x.shape) == x).all()
+    # inverse on arbitrary data vs oracle
+    ctx.ntt_inverse(d, npoly, L)
+    assert (d.to_numpy(x.shape) == octx.ntt(x, L, inverse=True)).all()
+    # explicit prime_index (rows under a permuted / repeated prime choice)
+    pidx = [L - 1 - i for i in range(L)]
+    y = np.stack([rng.integers(0, primes[p], size=n, dtype=np.uint64) for p in pidx])[None]
+    d2 = up(moai, y)
+    ctx.ntt_forward(d2, 1, L, prime_index=pidx)
+    assert (d2.to_numpy(y.shape) == octx.ntt(y, L, prime_index=pidx)).all()
+
+
+def octx_root(logn, q):
+    return O.Tables(logn, q).t.root
+
+
+@pytest.mark.parametrize("logn", [4, 12, 13, 16])
+def test_ntt_naive_stage_path_agrees(moai, logn, monkeypatch):
+    """the per-stage global-memory kernels (MOAI_NTT_NAIVE=1) and the tiled kernels are two
+    implementations of the same transform; both must equal the oracle."""
+    import subprocess, sys
+    code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import oracle as O, __graft_entry__ as g
+m = g.load_package()
+logn = int(sys.argv[1]); n = 1 << logn
+primes = O.coeff_modulus_create(n, [60, 46])
+octx, ctx = O.Context(logn, primes), m.Context(logn, primes)
+x = O.uniform_rns(np.random.default_rng(1), primes, (2,), n)
+d = m.DeviceBuffer.from_numpy(x)
+ctx.ntt_forward(d, 2, 2); assert (d.to_numpy(x.shape) == octx.ntt(x, 2)).all()
+ctx.ntt_inverse(d, 2, 2); assert (d.to_numpy(x.shape) == x).all()
+print("ok")
+'''
+    env = dict(os.environ, MOAI_NTT_NAIVE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, str(logn)], cwd=root, env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_elementwise(moai, env12):
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(3)
+    L, npoly = 4, 3
+    a = O.uniform_rns(rng, primes[:L], (npoly,), n)
+    b = O.uniform_rns(rng, primes[:L], (npoly,), n)
+    a[0, :, :8] = 0
+    b[0, :, :4] = 0
+    for i in range(L):
+        a[1, i, :8] = primes[i] - 1
+        b[1, i, :8] = primes[i] - 1
+    da, db = up(moai, a), up(moai, b)
+    do = moai.DeviceBuffer(a.size)
+    ctx.add(da, db, do, npoly, L)
+    assert (do.to_numpy(a.shape) == octx.add(a, b, npoly, L)).all()
+    ctx.sub(da, db, do, npoly, L)
+    assert (do.to_numpy(a.shape) == octx.sub(a, b, npoly, L)).all()
+    ctx.negate(da, do, npoly, L)
+    assert (do.to_numpy(a.shape) == octx.negate(a, npoly, L)).all()
+    ctx.dyadic_mul(da, db, do, npoly, npoly, L)
+    exp = np.stack([octx.multiply_plain(a[p], 1, L, b[p]).reshape(L, n) for p in range(npoly)])
+    assert (do.to_numpy(a.shape) == exp).all()
+    # broadcast plaintext (multiply_plain)
+    ctx.dyadic_mul(da, db, do, npoly, 1, L)
+    assert (do.to_numpy(a.shape) == octx.multiply_plain(a, npoly, L, b[0])).all()
+    # in place
+    ctx.add(da, db, da, npoly, L)
+    assert (da.to_numpy(a.shape) == octx.add(a, b, npoly, L)).all()
+    # scalar rows == multiply by a constant-row plaintext (ckks.cpp:131-150)
+    da = up(moai, a)
+    scal = [int(rng.integers(0, 1 << 63)) * 2 + 1 for _ in range(L)]
+    ctx.mul_scalar_rows(da, scal, do, npoly, L)
+    pt = np.stack([np.full(n, scal[i] % primes[i], dtype=np.uint64) for i in range(L)])
+    assert (do.to_numpy(a.shape) == octx.multiply_plain(a, npoly, L, pt)).all()
+    ctx.add_scalar_rows(da, scal, do, npoly, L)
+    ptb = np.broadcast_to(pt, a.shape)
+    assert (do.to_numpy(a.shape) == octx.add(a, np.ascontiguousarray(ptb), npoly, L)).all()
+
+
+def test_ct_multiply_square(moai, env12):
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(4)
+    L, B = 4, 2
+    x = O.uniform_rns(rng, primes[:L], (B, 2), n)
+    y = O.uniform_rns(rng, primes[:L], (B, 2), n)
+    dx, dy = up(moai, x), up(moai, y)
+    do = moai.DeviceBuffer(B * 3 * L * n)
+    ctx.ct_multiply(dx, dy, do, L, B)
+    got = do.to_numpy((B, 3, L, n))
+    for b in range(B):
+        assert (got[b] == octx.multiply(x[b], y[b], L)).all()
+    ctx.ct_square(dx, do, L, B)
+    got = do.to_numpy((B, 3, L, n))
+    for b in range(B):
+        assert (got[b] == octx.square(x[b], L)).all()
+
+
+@pytest.mark.parametrize("L", [5, 4, 2])
+def test_rescale_and_drop(moai, env12, L):
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(5 + L)
+    B, size = 2, 2
+    x = O.uniform_rns(rng, primes[:L], (B, size), n)
+    dx = up(moai, x)
+    do = moai.DeviceBuffer(B * size * (L - 1) * n)
+    ctx.rescale(dx, do, size, L, B)
+    got = do.to_numpy((B, size, L - 1, n))
+    for b in range(B):
+        assert (got[b] == octx.rescale(x[b], size, L)).all()
+    assert (dx.to_numpy(x.shape) == x).all()  # input preserved
+    for drop in range(1, L):
+        ctx.mod_drop(dx, do, size, L, drop, B)
+        got = do.to_numpy((B, size, L - drop, n), words=B * size * (L - drop) * n)
+        assert (got == x[:, :, : L - drop]).all()
+    with pytest.raises(moai.MoaiError):
+        ctx.mod_drop(dx, do, size, L, L, B)
+    if L == 2:
+        one = moai.DeviceBuffer(B * size * n)
+        ctx.mod_drop(dx, one, size, L, 1, B)
+        with pytest.raises(moai.MoaiError):  # end of modulus switching chain (evaluator.cpp:1693)
+            ctx.rescale(one, do, size, 1, B)
+
+
+def test_galois_permute(moai, env12):
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(6)
+    L = 3
+    x = O.uniform_rns(rng, primes[:L], (2,), n)
+    dx = up(moai, x)
+    do = moai.DeviceBuffer(x.size)
+    for step in (1, -1, 5, 0, 100):
+        elt = ctx.galois_elt_from_step(step)
+        assert elt == O.galois_elt_from_step(logn, step)
+        ctx.galois_permute(dx, do, 2, L, elt)
+        tab = O.galois_table_ntt(logn, elt)
+        assert (do.to_numpy(x.shape) == x[:, :, tab]).all()
+    with pytest.raises(moai.MoaiError):
+        ctx.galois_elt_from_step(n // 2)
+    with pytest.raises(moai.MoaiError):
+        ctx.galois_permute(dx, do, 2, L, 4)  # even element is not valid
+
+
+@pytest.mark.parametrize("L", [4, 3, 1])
+def test_switch_key_relin_galois(moai, env12, L):
+    logn, primes, octx, ctx = env12
+    n, k = 1 << logn, len(primes)
+    rng = np.random.default_rng(7 + L)
+    B = 3
+    key = O.uniform_rns(rng, primes, (k - 1, 2), n)
+    dkey = up(moai, key)
+    ct = O.uniform_rns(rng, primes[:L], (B, 2), n)
+    tgt = O.uniform_rns(rng, primes[:L], (B,), n)
+    dct, dt = up(moai, ct), up(moai, tgt)
+    ctx.switch_key(dct, dt, dkey, L, B)
+    got = dct.to_numpy(ct.shape)
+    for b in range(B):
+        assert (got[b] == octx.switch_key(ct[b], tgt[b], key, L).reshape(2, L, n)).all(), b
+    assert (dt.to_numpy(tgt.shape) == tgt).all()
+    # relinearize
+    ct3 = O.uniform_rns(rng, primes[:L], (B, 3), n)
+    d3 = up(moai, ct3)
+    do = moai.DeviceBuffer(B * 2 * L * n)
+    ctx.relinearize(d3, dkey, do, L, B)
+    got = do.to_numpy((B, 2, L, n))
+    for b in range(B):
+        assert (got[b] == octx.relinearize(ct3[b], key, L)).all()
+    # rotate / conjugate
+    for elt in (ctx.galois_elt_from_step(1), ctx.galois_elt_from_step(-3), 2 * n - 1):
+        dct = up(moai, ct)
+        ctx.apply_galois(dct, L, elt, dkey, B)
+        got = dct.to_numpy(ct.shape)
+        for b in range(B):
+            assert (got[b] == octx.apply_galois(ct[b], L, elt, key).reshape(2, L, n)).all()
+
+
+def test_keyswitch_decrypts(moai):
+    """semantic end-to-end: encrypt -> rotate on the GPU -> decrypt gives the rotated message."""
+    from ckks_toy import ToyClient, galois_coeffs
+    logn = 6
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, [51, 46, 46, 51, 58])
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    cl = ToyClient(octx, seed=3)
+    rng = np.random.default_rng(1)
+    m = [int(v) for v in rng.integers(-(1 << 30), 1 << 30, size=n)]
+    L = 4
+    ct = cl.encrypt(m, L)
+    elt = ctx.galois_elt_from_step(1)
+    gk = cl.galois_key(elt)
+    dct = up(moai, ct)
+    ctx.apply_galois(dct, L, elt, up(moai, gk), 1)
+    out = dct.to_numpy(ct.shape)
+    d = cl.decrypt(out, 2, L)
+    assert max(abs(a - b) for a, b in zip(d, galois_coeffs(m, elt, n))) < (1 << 16)
+    assert (out == octx.apply_galois(ct, L, elt, gk).reshape(out.shape)).all()
+
+
+def test_modraise(moai, env12):
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(9)
+    B, Lout = 2, 4
+    x = O.uniform_rns(rng, primes[:1], (B, 2), n)
+    x[0, 0, 0, :4] = [0, primes[0] // 2, primes[0] // 2 + 1, primes[0] - 1]
+    dx = up(moai, x)
+    do = moai.DeviceBuffer(B * 2 * Lout * n)
+    ctx.modraise(dx, do, Lout, B)
+    got = do.to_numpy((B, 2, Lout, n))
+    for b in range(B):
+        assert (got[b] == octx.modraise(x[b], Lout)).all()
+
+
+def test_moai_chain_level_ops_n16(moai):
+    """MOAI's real parameters (N = 2^16, the 36-prime chain): NTT on all 36 primes, rescale and one
+    key switch at a low level, against the oracle."""
+    logn = 16
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, MOAI_BITS)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    rng = np.random.default_rng(16)
+    k = len(primes)
+    x = O.uniform_rns(rng, primes, (1,), n)
+    d = up(moai, x)
+    ctx.ntt_forward(d, 1, k)
+    assert (d.to_numpy(x.shape) == octx.ntt(x, k, batch=True)).all()
+    ctx.ntt_inverse(d, 1, k)
+    assert (d.to_numpy(x.shape) == x).all()
+    L = 3
+    key = O.uniform_rns(rng, primes, (k - 1, 2), n)  # 1.3 GB, the reference's key size
+    ct = O.uniform_rns(rng, primes[:L], (1, 2), n)
+    dct = up(moai, ct)
+    elt = ctx.galois_elt_from_step(1)
+    ctx.apply_galois(dct, L, elt, up(moai, key), 1)
+    got = dct.to_numpy(ct.shape)
+    assert (got[0] == octx.apply_galois(ct[0], L, elt, key).reshape(2, L, n)).all()
+    do = moai.DeviceBuffer(2 * (L - 1) * n)
+    ctx.rescale(dct, do, 2, L, 1)
+    assert (do.to_numpy((2, L - 1, n)) == octx.rescale(got[0], 2, L)).all()
+
+
+def test_config2_shape_properties(moai):
+    """BASELINE config 2 shape (N = 2^16, 44 x 60-bit primes), reduced batch: forward result checked
+    against the oracle on every row of one ciphertext and by round trip + linearity on the batch."""
+    logn, L = 16, 44
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, [60] * L)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    rng = np.random.default_rng(1)
+    B = 4
+    x = O.uniform_rns(rng, primes, (B, 2), n)
+    y = O.uniform_rns(rng, primes, (B, 2), n)
+    dx, dy = up(moai, x), up(moai, y)
+    ds = moai.DeviceBuffer(x.size)
+    ctx.add(dx, dy, ds, B * 2, L)
+    ctx.ntt_forward(dx, B * 2, L)
+    ctx.ntt_forward(dy, B * 2, L)
+    ctx.ntt_forward(ds, B * 2, L)
+    fx = dx.to_numpy(x.shape)
+    assert (fx[0] == octx.ntt(x[0], L, batch=True)).all()
+    # linearity: NTT(x + y) == NTT(x) + NTT(y)
+    dl = moai.DeviceBuffer(x.size)
+    ctx.add(dx, dy, dl, B * 2, L)
+    assert (dl.to_numpy() == ds.to_numpy()).all()
+    ctx.ntt_inverse(dx, B * 2, L)
+    assert (dx.to_numpy(x.shape) == x).all()

@@ -1,0 +1,162 @@
+// valu_bench.hip -- measures the integer / fp64 VALU issue rates that bound a 64-bit modular
+// butterfly on gfx950 (MI355X).  Build: hipcc -O3 --offload-arch=gfx950 tools/valu_bench.hip -o tools/valu_bench
+// Output: one line per instruction: lane-ops per clock per CU (128 = full rate on 4 x SIMD32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define ITER 4096
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
+{
+    uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;
+    uint32_t a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;
+    uint32_t y = seed * 2654435761u + 12345u;
+    uint64_t w0 = a0, w1 = a1, w2 = a2, w3 = a3, w4 = a4, w5 = a5, w6 = a6, w7 = a7;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7, dy = 1.0000001;
+    for (int i = 0; i < ITER; ++i)
+    {
+        if (OP == 0)
+        {
+#define A(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(y));
+            A(a0) A(a1) A(a2) A(a3) A(a4) A(a5) A(a6) A(a7)
+#undef A
+        }
+        else if (OP == 1)
+        {
+#define A(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(y));
+            A(a0) A(a1) A(a2) A(a3) A(a4) A(a5) A(a6) A(a7)
+#undef A
+        }
+        else if (OP == 2)
+        {
+#define A(x) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(y));
+            A(a0) A(a1) A(a2) A(a3) A(a4) A(a5) A(a6) A(a7)
+#undef A
+        }
+        else if (OP == 3)
+        {
+#define A(x, w) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w) : "v"(x), "v"(y) : "vcc");
+            A(a0, w0) A(a1, w1) A(a2, w2) A(a3, w3) A(a4, w4) A(a5, w5) A(a6, w6) A(a7, w7)
+#undef A
+        }
+        else if (OP == 4)
+        {
+#define A(x) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(y));
+            A(a0) A(a1) A(a2) A(a3) A(a4) A(a5) A(a6) A(a7)
+#undef A
+        }
+        else if (OP == 5)
+        {
+#define A(x) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(x) : "v"(dy));
+            A(d0) A(d1) A(d2) A(d3) A(d4) A(d5) A(d6) A(d7)
+#undef A
+        }
+        else if (OP == 6)
+        {
+#define A(w) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w) : "v"(w7));
+            A(w0) A(w1) A(w2) A(w3) A(w4) A(w5) A(w6)
+            asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w7) : "v"(w0));
+#undef A
+        }
+        else if (OP == 7)
+        {
+            // full 64x64 -> high 64 (compiler-generated)
+#define A(w) w = __umul64hi(w, w7 | 1);
+            A(w0) A(w1) A(w2) A(w3) A(w4) A(w5) A(w6)
+#undef A
+            w7 += w0;
+        }
+        else if (OP == 8)
+        {
+            // Harvey/Shoup butterfly as used by the NTT kernels, 4 per iteration
+            const uint64_t q = 1152921504606584833ull, q2 = q * 2, tw = 288794978602139552ull, twq = 4620693217682128896ull;
+#define B(x, yv) { uint64_t u = x >= q2 ? x - q2 : x; uint64_t t = __umul64hi(yv, twq + w7); uint64_t v = yv * tw - t * q; x = u + v; yv = u + q2 - v; }
+            B(w0, w1) B(w2, w3) B(w4, w5) B(w6, w7)
+#undef B
+        }
+        else if (OP == 9)
+        {
+#define A(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x) : "v"(y));
+            A(a0) A(a1) A(a2) A(a3) A(a4) A(a5) A(a6) A(a7)
+#undef A
+        }
+    }
+    uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)(w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7) ^
+                 (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+    if (r == 0x12345678u)
+    {
+        out[0] = r;
+    }
+}
+
+template <int OP>
+int run(const char *name, double ops_per_iter, int cus, uint32_t *d)
+{
+    const int blocks = cus * 8;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1u);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r)
+    {
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 2u + r);
+    }
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    double total = (double)reps * blocks * 256.0 * ITER * ops_per_iter;
+    double per_s = total / (ms * 1e-3);
+    printf("%-28s %8.3f ms  %9.2f Gop/s  %7.2f lane-ops/clk/CU @2.4GHz\n", name, ms / reps, per_s * 1e-9,
+           per_s / (2.4e9 * cus));
+    return 0;
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    CHK(hipGetDeviceProperties(&p, 0));
+    printf("device: %s %s, %d CUs, clock %d kHz\n", p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate);
+    uint32_t *d;
+    CHK(hipMalloc(&d, 4096));
+    int cus = p.multiProcessorCount;
+    run<0>("v_add_u32", 8, cus, d);
+    run<1>("v_mul_lo_u32", 8, cus, d);
+    run<2>("v_mul_hi_u32", 8, cus, d);
+    run<3>("v_mad_u64_u32", 8, cus, d);
+    run<4>("v_mul_u32_u24", 8, cus, d);
+    run<9>("v_mad_u32_u24", 8, cus, d);
+    run<5>("v_fma_f64", 8, cus, d);
+    run<6>("v_lshl_add_u64 (64-bit add)", 8, cus, d);
+    run<7>("__umul64hi", 7, cus, d);
+    run<8>("shoup butterfly (64-bit)", 4, cus, d);
+    // HBM copy reference
+    {
+        size_t bytes = (size_t)2 << 30;
+        void *a, *b;
+        CHK(hipMalloc(&a, bytes));
+        CHK(hipMalloc(&b, bytes));
+        CHK(hipMemset(a, 1, bytes));
+        hipEvent_t e0, e1;
+        CHK(hipEventCreate(&e0));
+        CHK(hipEventCreate(&e1));
+        CHK(hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice));
+        CHK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i)
+        {
+            CHK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0));
+        }
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipEventSynchronize(e1));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        printf("hipMemcpy D2D 2 GiB: %.3f ms -> %.2f TB/s (read+write)\n", ms / 5, 2.0 * bytes * 5 / (ms * 1e-3) * 1e-12);
+    }
+    return 0;
+}

@@ -209,6 +209,18 @@ def is_prime(n):
     return True
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def load_traffic():
     """HBM bytes per forward-NTT launch pair from the committed PMC run (profiles/), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -226,6 +238,7 @@ def cpu_baseline(primes, seconds, sample_before, data, ctx, stream):
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
     import oracle as O  # checker + baseline only
 
     threads = O.lib().mo_max_threads()

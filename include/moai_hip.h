@@ -58,7 +58,7 @@ int moai_version(void);
  */
 int moai_ctx_create(int coeff_count_power, const uint64_t *primes, size_t k, int device, moai_ctx **out);
 void moai_ctx_destroy(moai_ctx *ctx);
-int moai_ctx_reserve(moai_ctx *ctx, size_t workspace_bytes);
+int moai_ctx_reserve(moai_ctx *ctx, size_t workspace_bytes); /* arena of the default (NULL) stream */
 size_t moai_ctx_coeff_count(const moai_ctx *ctx);
 size_t moai_ctx_prime_count(const moai_ctx *ctx);
 /* psi = minimal primitive 2N-th root of prime i (NTTTables::get_root) */
@@ -139,7 +139,8 @@ int moai_ct_square(moai_ctx *ctx, const uint64_t *x, uint64_t *out, size_t L, si
 int moai_rescale(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
                  void *stream);
 /* Evaluator::mod_switch_drop_to_next SEAL/evaluator.cpp:1483-1546 applied `drop` times:
- * in: [batch][size][L][N] -> out: [batch][size][L-drop][N].  out == in is allowed (compacts in place). */
+ * in: [batch][size][L][N] -> out: [batch][size][L-drop][N].  out must not alias in (except batch*size == 1,
+ * where the kept rows already are in place). */
 int moai_mod_drop(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,
                   size_t batch, void *stream);
 

@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -71,9 +72,14 @@ struct moai_ctx
     // inv_q_last_mod_q[l][i] = q_l^-1 mod q_i as Shoup operands, l in [1,k), i < l  (rns.cpp:769-775)
     moai::Tw *inv_qlast = nullptr;     // [k][k]
     std::vector<moai::Tw> inv_qlast_host;
-    // workspace arena
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
+    // workspace arenas, one per stream so that concurrent callers (MOAI's OpenMP threads, each on its
+    // own stream) never share scratch memory
+    struct Arena
+    {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<void *, Arena> ws;
     // Galois permutation tables, built lazily per element (galois.cpp:18-51)
     std::vector<uint32_t *> galois_tables; // [N] entries index (elt-1)>>1, device pointers
     void *mutex = nullptr;

@@ -334,7 +334,10 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
     (void)hipFree(c->inv_tw);
     (void)hipFree(c->pc);
     (void)hipFree(c->inv_qlast);
-    (void)hipFree(c->ws);
+    for (auto &kv : c->ws)
+    {
+        (void)hipFree(kv.second.ptr);
+    }
     for (uint32_t *t : c->galois_tables)
     {
         if (t)
@@ -346,33 +349,45 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
     delete c;
 }
 
+namespace moai {
+// grow the arena of `stream` to at least `bytes`; synchronises the device when it has to reallocate
+int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+    moai_ctx::Arena &a = c->ws[stream];
+    if (bytes > a.bytes)
+    {
+        MOAI_HIP_CHECK(hipDeviceSynchronize());
+        if (a.ptr)
+        {
+            MOAI_HIP_CHECK(hipFree(a.ptr));
+            a.ptr = nullptr;
+            a.bytes = 0;
+        }
+        hipError_t e = hipMalloc(&a.ptr, bytes);
+        if (e != hipSuccess)
+        {
+            a.ptr = nullptr;
+            return set_error(MOAI_ENOMEM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
+        }
+        a.bytes = bytes;
+    }
+    if (out)
+    {
+        *out = a.ptr;
+    }
+    return MOAI_OK;
+}
+} // namespace moai
+
 extern "C" int moai_ctx_reserve(moai_ctx *c, size_t bytes)
 {
     if (!c)
     {
         return set_error(MOAI_EINVAL, "null context");
     }
-    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
-    if (bytes <= c->ws_bytes)
-    {
-        return MOAI_OK;
-    }
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    (void)st;
-    MOAI_HIP_CHECK(hipDeviceSynchronize());
-    if (c->ws)
-    {
-        MOAI_HIP_CHECK(hipFree(c->ws));
-        c->ws = nullptr;
-        c->ws_bytes = 0;
-    }
-    hipError_t e = hipMalloc(&c->ws, bytes);
-    if (e != hipSuccess)
-    {
-        return set_error(MOAI_ENOMEM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
-    }
-    c->ws_bytes = bytes;
-    return MOAI_OK;
+    // reserves the arena of the default stream; other streams grow theirs on first use
+    return moai::reserve_for_stream(c, nullptr, bytes, nullptr);
 }
 
 extern "C" size_t moai_ctx_coeff_count(const moai_ctx *c)

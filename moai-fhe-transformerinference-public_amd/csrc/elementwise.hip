@@ -268,17 +268,19 @@ int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out)
 
 int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out)
 {
-    (void)s;
-    if (bytes > c->ws_bytes)
+    // per-stream arena; a first-time or larger request reallocates (with 25% headroom), which
+    // synchronises the device and therefore must not happen under stream capture
+    void *p = nullptr;
+    int rc = reserve_for_stream(c, (void *)s, bytes, &p);
+    if (rc == MOAI_OK && !p)
     {
-        // grow with 25% headroom; this synchronises the device and must not happen under capture
-        int rc = moai_ctx_reserve(c, bytes + bytes / 4);
-        if (rc)
-        {
-            return rc;
-        }
+        rc = reserve_for_stream(c, (void *)s, bytes + bytes / 4, &p);
     }
-    *out = c->ws;
+    if (rc)
+    {
+        return rc;
+    }
+    *out = p;
     return MOAI_OK;
 }
 

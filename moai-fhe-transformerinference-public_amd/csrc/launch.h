@@ -9,6 +9,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
                hipStream_t s);
 // returns the context workspace grown to at least `bytes` (grows only outside stream capture)
 int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out);
+int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out);
 // device pointer to the Galois permutation table of `elt` (built on first use)
 int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out);
 

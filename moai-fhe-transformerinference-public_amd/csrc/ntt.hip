@@ -92,6 +92,27 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
         MOAI_LAUNCH_CHECK();
         return MOAI_OK;
     }
+    // The two passes of one transform exchange the whole polynomial through memory.  Launching them
+    // per chunk of polynomials that fits the 256 MiB Infinity Cache lets the second pass read what
+    // the first one just wrote from the cache instead of HBM (MOAI_NTT_CHUNK_MB=0 disables).
+    size_t chunk = n_poly;
+    {
+        static long chunk_mb = -1;
+        if (chunk_mb < 0)
+        {
+            const char *e = getenv("MOAI_NTT_CHUNK_MB");
+            chunk_mb = e ? atol(e) : 0;
+        }
+        if (chunk_mb > 0)
+        {
+            size_t per_poly = L * c->n * sizeof(uint64_t);
+            chunk = ((size_t)chunk_mb << 20) / per_poly;
+            if (chunk < 1)
+            {
+                chunk = 1;
+            }
+        }
+    }
 #define MOAI_NTT_CASE(LG)               \
     case LG:                            \
         if (inverse)                    \
@@ -103,15 +124,20 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
             launch_fwd<LG>(a, s);       \
         }                               \
         break;
-    switch (logn)
+    for (size_t p0 = 0; p0 < n_poly; p0 += chunk)
     {
-        MOAI_NTT_CASE(12)
-        MOAI_NTT_CASE(13)
-        MOAI_NTT_CASE(14)
-        MOAI_NTT_CASE(15)
-        MOAI_NTT_CASE(16)
-    default:
-        return set_error(MOAI_ELOGIC, "unsupported poly_modulus_degree 2^%d", logn);
+        a.data = data + p0 * L * c->n;
+        a.n_poly = (uint32_t)(n_poly - p0 < chunk ? n_poly - p0 : chunk);
+        switch (logn)
+        {
+            MOAI_NTT_CASE(12)
+            MOAI_NTT_CASE(13)
+            MOAI_NTT_CASE(14)
+            MOAI_NTT_CASE(15)
+            MOAI_NTT_CASE(16)
+        default:
+            return set_error(MOAI_ELOGIC, "unsupported poly_modulus_degree 2^%d", logn);
+        }
     }
 #undef MOAI_NTT_CASE
     MOAI_LAUNCH_CHECK();

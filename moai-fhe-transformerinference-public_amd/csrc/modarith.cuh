@@ -60,6 +60,12 @@ __device__ __forceinline__ uint64_t barrett64(uint64_t x, uint64_t q, uint64_t c
 // dwthandler.h:110-163)
 __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
+#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
+    // diagnostic build only (tools/ablate.sh): data movement without the arithmetic
+    x += y + w;
+    y ^= wq + q + q2;
+    return;
+#endif
     uint64_t u = csub(x, q2);
     uint64_t v = mul_shoup_lazy(y, w, wq, q);
     x = u + v;
@@ -69,6 +75,11 @@ __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, ui
 // Gentleman-Sande butterfly, lazy: x, y in [0, 2q) -> [0, 2q)   (dwthandler.h:226-250)
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
+#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
+    x += y + w;
+    y ^= wq + q + q2;
+    return;
+#endif
     uint64_t u = x;
     uint64_t v = y;
     x = csub(u + v, q2);

@@ -37,6 +37,77 @@ static void launch_inv(const NttArgs &base, hipStream_t s)
     hipLaunchKernelGGL(ntt_inv_strided<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
 }
 
+static long env_long(const char *name, long dflt)
+{
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
+// single-launch transform (ntt_coop); its queue state lives in a per-stream arena
+static size_t coop_grid(const moai_ctx *c)
+{
+    static const long wpc = env_long("MOAI_NTT_COOP_WPC", 4);
+    return (size_t)c->num_cu * (size_t)(wpc > 0 ? wpc : 4);
+}
+
+static uint32_t coop_delay()
+{
+    static const long d = env_long("MOAI_NTT_COOP_DELAY", 4);
+    return (uint32_t)(d > 0 ? d : 1);
+}
+
+static size_t coop_steps_cap(const moai_ctx *c, size_t rows)
+{
+    return rows + coop_delay() + coop_grid(c) + 8;
+}
+
+static size_t coop_state_bytes(const moai_ctx *c, size_t rows)
+{
+    return sizeof(CoopState) + sizeof(uint32_t) * (rows + 8 * coop_steps_cap(c, rows));
+}
+
+template <int LOGN>
+static int launch_coop(moai_ctx *c, const NttArgs &base, bool inverse, void *state_mem, hipStream_t s)
+{
+    static const long occ = env_long("MOAI_NTT_COOP_OCC", 4);
+    NttArgs a = base;
+    const uint32_t rows = a.n_poly * a.L;
+    const uint32_t grid = (uint32_t)coop_grid(c);
+    CoopArgs ca;
+    ca.rows = rows;
+    ca.delay = coop_delay();
+    ca.steps_cap = (uint32_t)coop_steps_cap(c, rows);
+    ca.st = static_cast<CoopState *>(state_mem);
+    ca.done = reinterpret_cast<uint32_t *>(static_cast<char *>(state_mem) + sizeof(CoopState));
+    ca.rowmap = ca.done + rows;
+    MOAI_HIP_CHECK(hipMemsetAsync(state_mem, 0, coop_state_bytes(c, rows), s));
+    a.total_work = grid;
+    if (occ == 3)
+    {
+        if (inverse)
+        {
+            hipLaunchKernelGGL((ntt_coop<LOGN, true, 3>), dim3(grid), dim3(256), 0, s, a, ca);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ntt_coop<LOGN, false, 3>), dim3(grid), dim3(256), 0, s, a, ca);
+        }
+    }
+    else
+    {
+        if (inverse)
+        {
+            hipLaunchKernelGGL((ntt_coop<LOGN, true, 4>), dim3(grid), dim3(256), 0, s, a, ca);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ntt_coop<LOGN, false, 4>), dim3(grid), dim3(256), 0, s, a, ca);
+        }
+    }
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
 // data [n_poly][L][N]; rows maps row -> prime.  Returns a MOAI_* code.
 int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse, hipStream_t s)
 {
@@ -91,6 +162,34 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
         }
         MOAI_LAUNCH_CHECK();
         return MOAI_OK;
+    }
+    {
+        // default path: one persistent launch per transform, the two passes meeting in L2
+        static const long coop = env_long("MOAI_NTT_COOP", 1);
+        if (coop)
+        {
+            void *st = nullptr;
+            int rc = reserve_for_stream(c, (void *)((uintptr_t)s ^ 1u), coop_state_bytes(c, n_poly * L), &st);
+            if (rc)
+            {
+                return rc;
+            }
+            switch (logn)
+            {
+            case 12:
+                return launch_coop<12>(c, a, inverse, st, s);
+            case 13:
+                return launch_coop<13>(c, a, inverse, st, s);
+            case 14:
+                return launch_coop<14>(c, a, inverse, st, s);
+            case 15:
+                return launch_coop<15>(c, a, inverse, st, s);
+            case 16:
+                return launch_coop<16>(c, a, inverse, st, s);
+            default:
+                return set_error(MOAI_ELOGIC, "unsupported poly_modulus_degree 2^%d", logn);
+            }
+        }
     }
     // The two passes of one transform exchange the whole polynomial through memory.  Launching them
     // per chunk of polynomials that fits the 256 MiB Infinity Cache lets the second pass read what

@@ -69,25 +69,16 @@ struct NttArgs
 // =====================================================================================================
 // forward, strided pass: stages 0 .. LOGN-9
 // =====================================================================================================
+// one tile of the strided pass of row `rowp` (pointer to the row's coefficient 0)
 template <int LOGN>
-__global__ __launch_bounds__(256) void ntt_fwd_strided(NttArgs a)
+__device__ __forceinline__ void fwd_strided_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
+                                                 uint64_t q, uint64_t q2, uint64_t *lds, const uint32_t tid)
 {
     constexpr int R1 = LOGN - 8;
     constexpr int RB = R1 - 4;
     constexpr int GB = 12 - R1;
     constexpr uint32_t G = 1u << GB;
-    constexpr uint32_t TPR = 256u / G;
-    __shared__ uint64_t lds[RB > 0 ? 4096 : 1];
-
-    const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
-    const uint32_t tile = w % TPR;
-    const uint32_t prow = w / TPR;
-    const uint32_t prime = a.rows.idx[prow % a.L];
-    const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
-    const uint64_t q = a.pc[prime].q;
-    const uint64_t q2 = a.pc[prime].q2;
-    uint64_t *__restrict__ row = a.data + ((size_t)prow << LOGN) + tile * G;
-    const uint32_t tid = threadIdx.x;
+    uint64_t *__restrict__ row = rowp + tile * G;
 
     uint64_t x[16];
 #pragma unroll
@@ -160,28 +151,29 @@ __global__ __launch_bounds__(256) void ntt_fwd_strided(NttArgs a)
     }
 }
 
+template <int LOGN>
+__global__ __launch_bounds__(256) void ntt_fwd_strided(NttArgs a)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ uint64_t lds[4096];
+    const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t tile = w % TPR;
+    const uint32_t prow = w / TPR;
+    const uint32_t prime = a.rows.idx[prow % a.L];
+    fwd_strided_tile<LOGN>(a.data + ((size_t)prow << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc[prime].q,
+                           a.pc[prime].q2, lds, threadIdx.x);
+}
+
 // =====================================================================================================
 // forward, contiguous pass: stages LOGN-8 .. LOGN-1 on 16 consecutive 256-blocks; writes canonical
 // =====================================================================================================
 template <int LOGN>
-__global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
+__device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
+                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid)
 {
     constexpr int R1 = LOGN - 8;
-    constexpr uint32_t TPR = 1u << (LOGN - 12);
-    __shared__ ulonglong2 lds2[2048];
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
-
-    const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
-    const uint32_t pol = w % a.n_poly;
-    const uint32_t rest = w / a.n_poly;
-    const uint32_t tile = rest % TPR;
-    const uint32_t r = rest / TPR;
-    const uint32_t prime = a.rows.idx[r];
-    const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
-    const uint64_t q = a.pc[prime].q;
-    const uint64_t q2 = a.pc[prime].q2;
-    uint64_t *__restrict__ base = a.data + (((size_t)pol * a.L + r) << LOGN) + ((size_t)tile << 12);
-    const uint32_t tid = threadIdx.x;
+    uint64_t *__restrict__ base = rowp + ((size_t)tile << 12);
     const uint32_t b = tid >> 4;
     const uint32_t tl = tid & 15u;
     const uint32_t blk = (tile << 4) + b;
@@ -255,28 +247,31 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
     }
 }
 
-// =====================================================================================================
-// inverse, contiguous pass: stages LOGN-1 .. LOGN-8 (gap 1 .. 128); lazy [0,2q) out
-// =====================================================================================================
 template <int LOGN>
-__global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
+__global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 {
-    constexpr int R1 = LOGN - 8;
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ ulonglong2 lds2[2048];
-    uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
-
     const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t pol = w % a.n_poly;
     const uint32_t rest = w / a.n_poly;
     const uint32_t tile = rest % TPR;
     const uint32_t r = rest / TPR;
     const uint32_t prime = a.rows.idx[r];
-    const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
-    const uint64_t q = a.pc[prime].q;
-    const uint64_t q2 = a.pc[prime].q2;
-    uint64_t *__restrict__ base = a.data + (((size_t)pol * a.L + r) << LOGN) + ((size_t)tile << 12);
-    const uint32_t tid = threadIdx.x;
+    fwd_contig_tile<LOGN>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
+                          a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x);
+}
+
+// =====================================================================================================
+// inverse, contiguous pass: stages LOGN-1 .. LOGN-8 (gap 1 .. 128); lazy [0,2q) out
+// =====================================================================================================
+template <int LOGN>
+__device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
+                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid)
+{
+    constexpr int R1 = LOGN - 8;
+    uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
+    uint64_t *__restrict__ base = rowp + ((size_t)tile << 12);
     const uint32_t b = tid >> 4;
     const uint32_t tl = tid & 15u;
     const uint32_t blk = (tile << 4) + b;
@@ -350,29 +345,35 @@ __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
     }
 }
 
+template <int LOGN>
+__global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ ulonglong2 lds2[2048];
+    const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t pol = w % a.n_poly;
+    const uint32_t rest = w / a.n_poly;
+    const uint32_t tile = rest % TPR;
+    const uint32_t r = rest / TPR;
+    const uint32_t prime = a.rows.idx[r];
+    inv_contig_tile<LOGN>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
+                          a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x);
+}
+
 // =====================================================================================================
 // inverse, strided pass: stages LOGN-9 .. 0, N^-1 folded into stage 0; writes canonical
 // =====================================================================================================
 template <int LOGN>
-__global__ __launch_bounds__(256) void ntt_inv_strided(NttArgs a)
+__device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
+                                                 const PrimeConst *pc, uint64_t *lds, const uint32_t tid)
 {
     constexpr int R1 = LOGN - 8;
     constexpr int RB = R1 - 4;
     constexpr int GB = 12 - R1;
     constexpr uint32_t G = 1u << GB;
-    constexpr uint32_t TPR = 256u / G;
-    __shared__ uint64_t lds[RB > 0 ? 4096 : 1];
-
-    const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
-    const uint32_t tile = w % TPR;
-    const uint32_t prow = w / TPR;
-    const uint32_t prime = a.rows.idx[prow % a.L];
-    const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
-    const PrimeConst *pc = a.pc + prime;
     const uint64_t q = pc->q;
     const uint64_t q2 = pc->q2;
-    uint64_t *__restrict__ row = a.data + ((size_t)prow << LOGN) + tile * G;
-    const uint32_t tid = threadIdx.x;
+    uint64_t *__restrict__ row = rowp + tile * G;
 
     uint64_t x[16];
     if (RB > 0)
@@ -449,6 +450,205 @@ __global__ __launch_bounds__(256) void ntt_inv_strided(NttArgs a)
     {
         uint32_t e = (uint32_t)j * 256u + tid;
         row[((e >> GB) << 8) + (e & (G - 1))] = csub(x[j], q);
+    }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void ntt_inv_strided(NttArgs a)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ uint64_t lds[4096];
+    const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t tile = w % TPR;
+    const uint32_t prow = w / TPR;
+    const uint32_t prime = a.rows.idx[prow % a.L];
+    inv_strided_tile<LOGN>(a.data + ((size_t)prow << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc + prime, lds, threadIdx.x);
+}
+
+// =====================================================================================================
+// single-launch transform: both passes of a row meet in one XCD's L2
+// =====================================================================================================
+// The two passes exchange the whole row (N x 8 B) and no CU can hold a 512 KiB row, but an XCD's
+// 4 MiB L2 can.  This persistent kernel therefore keeps all work on one row inside one XCD: every
+// workgroup reads the id of the XCD it runs on (HW_REG_XCC_ID) and pulls (row, pass, tile) items from
+// that XCD's own queue with one fetch-add per item; rows are claimed from a global ticket by the
+// workgroup that draws tile 0 of a step.  Queue order per XCD, in steps of 2*TPR items:
+//     [first-pass tiles of step s][second-pass tiles of step s - DELAY]
+// so a row's second pass follows its first pass by DELAY rows: long enough that the first pass has
+// normally finished, short enough that the row is still in L2.  A first-pass tile publishes with
+// "s_waitcnt vmcnt(0); barrier; one lane bumps done[row]" (its stores have then reached L2); a
+// second-pass tile waits for done[row] == TPR, drops its CU's L1 (agent-scope acquire) and reads the
+// row from L2.  HBM then sees one read and one write per coefficient instead of two of each.
+//
+// Correctness does not depend on dispatch order or placement:
+//  * a row's items are only ever handed out by the queue of the XCD that claimed the row, so producer
+//    and consumer share an L2 by construction (not by an assumption about the dispatcher);
+//  * a workgroup blocks only on items that sit EARLIER in its own queue, i.e. on workgroups that are
+//    already running and never block themselves (first-pass tiles, the row claim), so there is no
+//    co-residency requirement and no deadlock for any grid size >= 1;
+//  * every spin is bounded; a timeout sets CoopState::error (checked by the host) instead of hanging.
+struct CoopState
+{
+    uint32_t next_row; // global row ticket
+    uint32_t error;    // non-zero after a spin timeout
+    uint32_t pad0[30];
+    struct
+    {
+        uint32_t head;
+        uint32_t pad[31];
+    } q[8];
+    // followed by: uint32_t done[rows]; uint32_t rowmap[8][steps_cap]
+};
+
+struct CoopArgs
+{
+    CoopState *st;
+    uint32_t *done;     // [rows] first-pass tiles completed
+    uint32_t *rowmap;   // [8][steps_cap]: 0 = unset, 1 = end of work, r + 2 = row r
+    uint32_t rows;      // n_poly * L
+    uint32_t steps_cap;
+    uint32_t delay;     // steps between a row's first and second pass in the queue
+};
+
+#define MOAI_SPIN_LIMIT (1u << 22)
+
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 7u;
+}
+
+__device__ __forceinline__ uint32_t ld_relaxed(uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int LOGN, bool INV, int WPS>
+__global__ __launch_bounds__(256, WPS) void ntt_coop(NttArgs a, CoopArgs c)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ ulonglong2 lds2[2048];
+    __shared__ uint32_t sh[2];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t xcc = xcc_id();
+    uint32_t *rowmap = c.rowmap + (size_t)xcc * c.steps_cap;
+
+    for (;;)
+    {
+        __syncthreads(); // LDS tile and sh[] of the previous item are dead
+        // opaque copy of the thread index: stops the compiler from hoisting the ~70 per-thread address
+        // computations of both tile bodies out of this loop and spilling them
+        uint32_t tid = tid0;
+        asm volatile("" : "+v"(tid));
+        if (tid == 0)
+        {
+            const uint32_t it = __hip_atomic_fetch_add(&c.st->q[xcc].head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t step = it / (2 * TPR);
+            const uint32_t rem = it % (2 * TPR);
+            const uint32_t pass = rem / TPR;
+            const uint32_t tile = rem % TPR;
+            uint32_t v = 0; // 0 = empty slot, 1 = end of work, r + 2 = row r
+            if (!(pass == 1 && step < c.delay))
+            {
+                const uint32_t sr = pass ? step - c.delay : step;
+                if (sr >= c.steps_cap)
+                {
+                    v = 1;
+                }
+                else if (pass == 0 && tile == 0)
+                {
+                    uint32_t r = __hip_atomic_fetch_add(&c.st->next_row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = r < c.rows ? r + 2 : 1;
+                    __hip_atomic_store(&rowmap[sr], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                else
+                {
+                    uint32_t i = 0;
+                    while ((v = ld_relaxed(&rowmap[sr])) == 0 && ++i < MOAI_SPIN_LIMIT)
+                    {
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (v == 0)
+                    {
+                        __hip_atomic_store(&c.st->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = 1;
+                    }
+                }
+                if (v >= 2 && pass == 1)
+                {
+                    // wait for the TPR first-pass tiles of this row, then drop this CU's L1
+                    uint32_t *d = &c.done[v - 2];
+                    uint32_t i = 0;
+                    while (ld_relaxed(d) < TPR && ++i < MOAI_SPIN_LIMIT)
+                    {
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (i >= MOAI_SPIN_LIMIT)
+                    {
+                        __hip_atomic_store(&c.st->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = 1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            sh[0] = v;
+            sh[1] = (pass << 16) | tile;
+        }
+        __syncthreads();
+        // wave-uniform by construction: keep them in SGPRs so that row / twiddle bases stay scalar
+        const uint32_t v = __builtin_amdgcn_readfirstlane(sh[0]);
+        const uint32_t pt = __builtin_amdgcn_readfirstlane(sh[1]);
+        const uint32_t pass = pt >> 16;
+        const uint32_t tile = pt & 0xffffu;
+        if (v == 0)
+        {
+            continue;
+        }
+        if (v == 1)
+        {
+            if (pass == 1)
+            {
+                return; // the rows behind this point of the queue do not exist
+            }
+            continue;
+        }
+        const uint32_t prow = v - 2;
+        const uint32_t prime = a.rows.idx[prow % a.L];
+        const Tw *tw = a.tw + ((size_t)prime << LOGN);
+        const PrimeConst *pc = a.pc + prime;
+        uint64_t *rowp = a.data + ((size_t)prow << LOGN);
+        if (pass == 0)
+        {
+            if (INV)
+            {
+                inv_contig_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds2, tid);
+            }
+            else
+            {
+                fwd_strided_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds, tid);
+            }
+            // publish: every wave's stores have reached L2, then one lane bumps the row counter
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+            {
+                __hip_atomic_fetch_add(&c.done[prow], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        else
+        {
+            if (INV)
+            {
+                inv_strided_tile<LOGN>(rowp, tile, tw, pc, lds, tid);
+            }
+            else
+            {
+                fwd_contig_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds2, tid);
+            }
+        }
     }
 }
 

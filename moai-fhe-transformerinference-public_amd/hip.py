@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmoai_hip.so")
+_SO = os.environ.get("MOAI_HIP_LIB") or os.path.join(_HERE, "libmoai_hip.so")  # override: diagnostic builds only
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

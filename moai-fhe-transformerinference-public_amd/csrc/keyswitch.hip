@@ -17,8 +17,10 @@
 // The loop over I is outermost so that the 2*L key rows of modulus I are read once per batch.
 #include <mutex>
 
+#include <cstdlib>
+
 #include "launch.h"
-#include "modarith.cuh"
+#include "keyswitch_kernels.cuh"
 
 namespace moai {
 
@@ -306,11 +308,78 @@ static int check_level(const moai_ctx *c, size_t L, size_t polys)
     return MOAI_OK;
 }
 
+// number of output moduli whose digits are in flight at once: bounded by the scratch budget
+// (MOAI_KS_TMP_MB, default 2048 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
+// one launch while large batches stay within a few GiB of workspace
+static size_t ks_group_size(const moai_ctx *c, size_t L, size_t batch)
+{
+    static long budget_mb = -1;
+    if (budget_mb < 0)
+    {
+        const char *e = getenv("MOAI_KS_TMP_MB");
+        budget_mb = e ? atol(e) : 2048;
+        if (budget_mb < 1)
+        {
+            budget_mb = 1;
+        }
+    }
+    const size_t per_modulus = batch * L * c->n * sizeof(uint64_t);
+    size_t g = ((size_t)budget_mb << 20) / (per_modulus ? per_modulus : 1);
+    if (g < 1)
+    {
+        g = 1;
+    }
+    if (g > L + 1)
+    {
+        g = L + 1;
+    }
+    return g;
+}
+
+static size_t ks_tmp_rows(const moai_ctx *c, size_t L, size_t batch)
+{
+    size_t fused = c->logn >= 12 ? batch * ks_group_size(c, L, batch) * L : 0;
+    size_t plain = 2 * batch * L; // ops [B][L] (unfused path) and u [2B][L] (mod-down)
+    return fused > plain ? fused : plain;
+}
+
 static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
 {
     const size_t row_bytes = c->n * sizeof(uint64_t);
-    return align256(batch * L * row_bytes) + align256(2 * batch * L * row_bytes) +
+    return align256(batch * L * row_bytes) + align256(ks_tmp_rows(c, L, batch) * row_bytes) +
            align256(batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
+}
+
+template <int LOGN>
+static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
+                          size_t batch, const KsGroup &grp, size_t G, hipStream_t s)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    KsP1Args p1;
+    p1.t = t;
+    p1.tmp = tmp;
+    p1.tw = c->fwd_tw;
+    p1.pc = c->pc;
+    p1.grp = grp;
+    p1.L = (uint32_t)L;
+    p1.G = (uint32_t)G;
+    p1.total_work = (uint32_t)(batch * G * L * TPR);
+    hipLaunchKernelGGL(ks_fwd_strided<LOGN>, dim3(p1.total_work), dim3(256), 0, s, p1);
+    MOAI_LAUNCH_CHECK();
+    KsP2Args p2;
+    p2.tmp = tmp;
+    p2.key = key;
+    p2.acc = acc;
+    p2.tw = c->fwd_tw;
+    p2.pc = c->pc;
+    p2.grp = grp;
+    p2.L = (uint32_t)L;
+    p2.G = (uint32_t)G;
+    p2.k = (uint32_t)c->k;
+    p2.total_work = (uint32_t)(batch * G * TPR);
+    hipLaunchKernelGGL(ks_contig_mac<LOGN>, dim3(p2.total_work), dim3(256), 0, s, p2);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
 }
 
 // target row block of ciphertext b starts at target + (b * target_stride_rows + target_off_rows) * N.
@@ -331,7 +400,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     }
     const size_t row_bytes = n * sizeof(uint64_t);
     const size_t sz_t = align256(batch * L * row_bytes);
-    const size_t sz_ops = align256(2 * batch * L * row_bytes); // also holds u [2B][L][N]
+    const size_t sz_ops = align256(ks_tmp_rows(c, L, batch) * row_bytes); // digits in flight; later u [2B][L][N]
     const size_t sz_acc = align256(batch * 2 * (L + 1) * row_bytes);
     uint64_t *t = static_cast<uint64_t *>(wsp);
     uint64_t *ops = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_t);
@@ -355,32 +424,78 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         return rc;
     }
     // 2. inner products per output modulus    (evaluator.cpp:2817-2911)
-    for (size_t Iidx = 0; Iidx <= L; ++Iidx)
+    if (c->logn >= 12)
     {
-        const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
-        hipLaunchKernelGGL(reduce_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, t, ops, c->pc, prime, n2);
-        MOAI_LAUNCH_CHECK();
-        for (size_t r = 0; r < L; ++r)
+        // fused: "mod q_I" rides on the strided pass's loads, the key MAC on the contiguous pass
+        const size_t G = ks_group_size(c, L, batch);
+        if (batch * G * L * (n >> 12) > 0x7fffffffull)
         {
-            rm.idx[r] = (uint16_t)prime;
+            return set_error(MOAI_EINVAL, "batch too large for one launch");
         }
-        rc = ntt_launch(c, ops, batch, L, rm, false, s);
-        if (rc)
+        for (size_t I0 = 0; I0 <= L; I0 += G)
         {
-            return rc;
+            const size_t g = (L + 1 - I0) < G ? (L + 1 - I0) : G;
+            KsGroup grp;
+            for (size_t i = 0; i < MOAI_MAX_RNS; ++i)
+            {
+                size_t Iidx = I0 + (i < g ? i : 0);
+                grp.prime[i] = (uint16_t)(Iidx == L ? k - 1 : Iidx);
+                grp.slot[i] = (uint16_t)Iidx;
+            }
+            switch (c->logn)
+            {
+            case 12:
+                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, s);
+                break;
+            case 13:
+                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, s);
+                break;
+            case 14:
+                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, s);
+                break;
+            case 15:
+                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, s);
+                break;
+            default:
+                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, s);
+                break;
+            }
+            if (rc)
+            {
+                return rc;
+            }
         }
-        MacArgs m;
-        m.ops = ops;
-        m.key = key;
-        m.acc = acc;
-        m.pc = c->pc;
-        m.L = (uint32_t)L;
-        m.k = (uint32_t)k;
-        m.prime = prime;
-        m.slot = (uint32_t)Iidx;
-        m.n2 = n2;
-        hipLaunchKernelGGL(keyswitch_mac_kernel, rgrid(c, batch), dim3(256), 0, s, m);
-        MOAI_LAUNCH_CHECK();
+    }
+    else
+    {
+        // small transforms (N <= 2048): separate reduce -> NTT -> MAC launches
+        for (size_t Iidx = 0; Iidx <= L; ++Iidx)
+        {
+            const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+            hipLaunchKernelGGL(reduce_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, t, ops, c->pc, prime, n2);
+            MOAI_LAUNCH_CHECK();
+            for (size_t r = 0; r < L; ++r)
+            {
+                rm.idx[r] = (uint16_t)prime;
+            }
+            rc = ntt_launch(c, ops, batch, L, rm, false, s);
+            if (rc)
+            {
+                return rc;
+            }
+            MacArgs m;
+            m.ops = ops;
+            m.key = key;
+            m.acc = acc;
+            m.pc = c->pc;
+            m.L = (uint32_t)L;
+            m.k = (uint32_t)k;
+            m.prime = prime;
+            m.slot = (uint32_t)Iidx;
+            m.n2 = n2;
+            hipLaunchKernelGGL(keyswitch_mac_kernel, rgrid(c, batch), dim3(256), 0, s, m);
+            MOAI_LAUNCH_CHECK();
+        }
     }
     // 3. mod-down by the special prime, accumulated into ct   (evaluator.cpp:2913-3018)
     hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc, last, 1u, (uint32_t)(L + 1),

@@ -1,0 +1,212 @@
+// keyswitch_kernels.cuh -- the key-switch inner product with the NTT passes fused around it.
+//
+// Reference loop (SEAL/evaluator.cpp:2817-2911), for every output modulus I and digit J:
+//     operand = NTT_{q_I}( t_J mod q_I ) ;  acc_{K,I} += operand (*) key[J][K][I]
+// On the device the "mod q_I" is applied while the strided pass loads the digit (ks_fwd_strided), and
+// the contiguous pass never writes the transformed digit back: one workgroup owns a 4096-coefficient
+// tile of the output (modulus I, ciphertext b), loops over the L digits, finishes each digit's last 8
+// stages in registers and multiplies it straight into 128-bit accumulators for both key components
+// (ks_contig_mac).  Per (I, J) coefficient this moves 8 B (read t) + 16 B (intermediate) + 16 B (key,
+// shared by the batch through L2) instead of 56 B + key for the unfused sequence
+// reduce -> NTT -> NTT -> MAC.
+#pragma once
+#include "ntt_kernels.cuh"
+
+namespace moai {
+
+struct KsGroup
+{
+    uint16_t prime[MOAI_MAX_RNS]; // context prime of group member g
+    uint16_t slot[MOAI_MAX_RNS];  // row of acc it produces (I, or L for the special prime)
+};
+
+struct KsP1Args
+{
+    const uint64_t *t;  // [B][L][N] digits in coefficient form
+    uint64_t *tmp;      // [B][G][L][N] after the strided pass, lazy [0,4q)
+    const Tw *tw;
+    const PrimeConst *pc;
+    KsGroup grp;
+    uint32_t L;
+    uint32_t G;
+    uint32_t total_work;
+};
+
+// work id -> (tile fastest, then group member, digit, ciphertext): neighbours read the same digit tile
+template <int LOGN>
+__global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ uint64_t lds[4096];
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t tile = w % TPR;
+    w /= TPR;
+    const uint32_t g = w % a.G;
+    w /= a.G;
+    const uint32_t J = w % a.L;
+    const uint32_t b = w / a.L;
+    const uint32_t prime = a.grp.prime[g];
+    const PrimeConst *pc = a.pc + prime;
+    LoadBarrett op;
+    op.q = pc->q;
+    op.cr1 = pc->cr1;
+    const uint64_t *in = a.t + (((size_t)b * a.L + J) << LOGN);
+    uint64_t *out = a.tmp + ((((size_t)b * a.G + g) * a.L + J) << LOGN);
+    fwd_strided_tile<LOGN, LoadBarrett>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds, threadIdx.x,
+                                        op);
+}
+
+struct KsP2Args
+{
+    const uint64_t *tmp; // [B][G][L][N]
+    const uint64_t *key; // [k-1][2][k][N]
+    uint64_t *acc;       // [B][2][L+1][N]
+    const Tw *tw;
+    const PrimeConst *pc;
+    KsGroup grp;
+    uint32_t L;
+    uint32_t G;
+    uint32_t k;
+    uint32_t total_work;
+};
+
+__device__ __forceinline__ void mac128r(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
+{
+    uint64_t pl = a * b;
+    uint64_t ph = mulhi64(a, b);
+    lo += pl;
+    hi += ph + (lo < pl ? 1 : 0);
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
+{
+    constexpr int R1 = LOGN - 8;
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ ulonglong2 lds2[2048];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
+
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t tile = w % TPR;
+    w /= TPR;
+    const uint32_t g = w % a.G;
+    const uint32_t bq = w / a.G;
+    const uint32_t prime = a.grp.prime[g];
+    const uint32_t slot = a.grp.slot[g];
+    const PrimeConst *pc = a.pc + prime;
+    const uint64_t q = pc->q, q2 = pc->q2;
+    const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = tid >> 4;
+    const uint32_t tl = tid & 15u;
+    const uint32_t blk = (tile << 4) + b;
+    const uint32_t myrow = tid;
+
+    uint64_t lo0[16], hi0[16], lo1[16], hi1[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+    {
+        lo0[e] = hi0[e] = lo1[e] = hi1[e] = 0;
+    }
+
+    for (uint32_t J = 0; J < a.L; ++J)
+    {
+        const uint64_t *__restrict__ base = a.tmp + ((((size_t)bq * a.G + g) * a.L + J) << LOGN) + ((size_t)tile << 12);
+        uint64_t x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+            x[j] = base[(b << 8) | ((uint32_t)j << 4) | tl];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            const int half = 8 >> u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+            {
+                if (!(j & half))
+                {
+                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
+                    ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+            lds[phys_contig((b << 8) | ((uint32_t)j << 4) | tl)] = x[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+        {
+            ulonglong2 v = lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))];
+            x[2 * c] = v.x;
+            x[2 * c + 1] = v.y;
+        }
+#pragma unroll
+        for (int u = 4; u < 8; ++u)
+        {
+            const int half = 8 >> (u - 4);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+            {
+                if (!(j & half))
+                {
+                    uint32_t t_ = (tl << 4) | (uint32_t)j;
+                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
+                    ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                }
+            }
+        }
+        // rows are private to their thread: write the canonical values back into the same slots
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+        {
+            ulonglong2 v;
+            v.x = csub(csub(x[2 * c], q2), q);
+            v.y = csub(csub(x[2 * c + 1], q2), q);
+            lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
+        }
+        __syncthreads();
+        // coalesced view of the tile: chunk ch = it * 256 + tid; multiply into both key components
+        const ulonglong2 *__restrict__ k0 =
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 11);
+        const ulonglong2 *__restrict__ k1 =
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN)) + ((size_t)tile << 11);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+        {
+            uint32_t ch = (uint32_t)it * 256u + tid;
+            uint32_t rr = ch >> 3;
+            ulonglong2 v = lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))];
+            ulonglong2 ka = k0[ch];
+            ulonglong2 kb = k1[ch];
+            mac128r(lo0[2 * it], hi0[2 * it], v.x, ka.x);
+            mac128r(lo0[2 * it + 1], hi0[2 * it + 1], v.y, ka.y);
+            mac128r(lo1[2 * it], hi1[2 * it], v.x, kb.x);
+            mac128r(lo1[2 * it + 1], hi1[2 * it + 1], v.y, kb.y);
+        }
+        __syncthreads(); // the tile is dead: the next digit may overwrite it
+    }
+    const uint64_t cr0 = pc->cr0, cr1 = pc->cr1;
+    ulonglong2 *__restrict__ o0 =
+        reinterpret_cast<ulonglong2 *>(a.acc + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN)) + ((size_t)tile << 11);
+    ulonglong2 *__restrict__ o1 =
+        reinterpret_cast<ulonglong2 *>(a.acc + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN)) + ((size_t)tile << 11);
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+    {
+        uint32_t ch = (uint32_t)it * 256u + tid;
+        ulonglong2 r0, r1;
+        r0.x = barrett128(lo0[2 * it], hi0[2 * it], q, cr0, cr1);
+        r0.y = barrett128(lo0[2 * it + 1], hi0[2 * it + 1], q, cr0, cr1);
+        r1.x = barrett128(lo1[2 * it], hi1[2 * it], q, cr0, cr1);
+        r1.y = barrett128(lo1[2 * it + 1], hi1[2 * it + 1], q, cr0, cr1);
+        o0[ch] = r0;
+        o1[ch] = r1;
+    }
+}
+
+} // namespace moai

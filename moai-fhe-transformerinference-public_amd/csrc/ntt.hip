@@ -164,8 +164,11 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
         return MOAI_OK;
     }
     {
-        // default path: one persistent launch per transform, the two passes meeting in L2
-        static const long coop = env_long("MOAI_NTT_COOP", 1);
+        // opt-in (MOAI_NTT_COOP=1): one persistent launch per transform, the two passes meeting in L2.
+        // Measured on MI355X (round 1): no faster than two launches -- L2 is write-through, so only the
+        // second-pass reads could be saved, and keeping enough rows in flight to avoid dependency stalls
+        // overflows the 4 MiB L2.
+        static const long coop = env_long("MOAI_NTT_COOP", 0);
         if (coop)
         {
             void *st = nullptr;

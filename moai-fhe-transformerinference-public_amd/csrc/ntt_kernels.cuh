@@ -69,23 +69,44 @@ struct NttArgs
 // =====================================================================================================
 // forward, strided pass: stages 0 .. LOGN-9
 // =====================================================================================================
-// one tile of the strided pass of row `rowp` (pointer to the row's coefficient 0)
-template <int LOGN>
-__device__ __forceinline__ void fwd_strided_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
-                                                 uint64_t q, uint64_t q2, uint64_t *lds, const uint32_t tid)
+struct LoadIdentity
+{
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return v;
+    }
+};
+
+// v mod q on load (modulo_poly_coeffs, SEAL/util/polyarithsmallmod.cpp:18-41): the key switch feeds
+// digits that are canonical under another prime (SEAL/evaluator.cpp:2844-2854)
+struct LoadBarrett
+{
+    uint64_t q, cr1;
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return barrett64(v, q, cr1);
+    }
+};
+
+// one tile of the strided pass: reads row `inp`, writes row `outp` (may be the same row)
+template <int LOGN, class LoadOp = LoadIdentity>
+__device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
+                                                 const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
+                                                 const uint32_t tid, LoadOp op = LoadOp())
 {
     constexpr int R1 = LOGN - 8;
     constexpr int RB = R1 - 4;
     constexpr int GB = 12 - R1;
     constexpr uint32_t G = 1u << GB;
     uint64_t *__restrict__ row = rowp + tile * G;
+    const uint64_t *__restrict__ irow = inp + tile * G;
 
     uint64_t x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {
         uint32_t e = (uint32_t)j * 256u + tid;
-        x[j] = row[((e >> GB) << 8) + (e & (G - 1))];
+        x[j] = op(irow[((e >> GB) << 8) + (e & (G - 1))]);
     }
     // phase A: top four bits of t live in the register index
 #pragma unroll
@@ -152,7 +173,7 @@ __device__ __forceinline__ void fwd_strided_tile(uint64_t *__restrict__ rowp, ui
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(256) void ntt_fwd_strided(NttArgs a)
+__global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
@@ -160,8 +181,9 @@ __global__ __launch_bounds__(256) void ntt_fwd_strided(NttArgs a)
     const uint32_t tile = w % TPR;
     const uint32_t prow = w / TPR;
     const uint32_t prime = a.rows.idx[prow % a.L];
-    fwd_strided_tile<LOGN>(a.data + ((size_t)prow << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc[prime].q,
-                           a.pc[prime].q2, lds, threadIdx.x);
+    uint64_t *rowp = a.data + ((size_t)prow << LOGN);
+    fwd_strided_tile<LOGN>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), a.pc[prime].q, a.pc[prime].q2, lds,
+                           threadIdx.x);
 }
 
 // =====================================================================================================
@@ -454,7 +476,7 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(256) void ntt_inv_strided(NttArgs a)
+__global__ __launch_bounds__(256, 5) void ntt_inv_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
@@ -628,7 +650,7 @@ __global__ __launch_bounds__(256, WPS) void ntt_coop(NttArgs a, CoopArgs c)
             }
             else
             {
-                fwd_strided_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds, tid);
+                fwd_strided_tile<LOGN>(rowp, rowp, tile, tw, pc->q, pc->q2, lds, tid);
             }
             // publish: every wave's stores have reached L2, then one lane bumps the row counter
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -92,6 +92,48 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
     }
 }
 
+template <int NT>
+__global__ __launch_bounds__(256) void copyk(const ulonglong2 *__restrict__ a, ulonglong2 *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    {
+        if (NT)
+        {
+            ulonglong2 v;
+            v.x = __builtin_nontemporal_load(&a[i].x);
+            v.y = __builtin_nontemporal_load(&a[i].y);
+            __builtin_nontemporal_store(v.x, &b[i].x);
+            __builtin_nontemporal_store(v.y, &b[i].y);
+        }
+        else
+        {
+            b[i] = a[i];
+        }
+    }
+}
+
+// in-place read-modify-write of 32 KiB tiles, one tile per workgroup iteration (the NTT's access shape)
+template <int UNROLL>
+__global__ __launch_bounds__(256) void rmwk(ulonglong2 *__restrict__ a, size_t ntiles)
+{
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+    {
+        ulonglong2 *p = a + t * 2048;
+        ulonglong2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            v[j] = p[j * 256 + threadIdx.x];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            v[j].x += 1;
+            p[j * 256 + threadIdx.x] = v[j];
+        }
+    }
+}
+
 template <int OP>
 int run(const char *name, double ops_per_iter, int cus, uint32_t *d)
 {
@@ -157,6 +199,39 @@ int main()
         float ms;
         CHK(hipEventElapsedTime(&ms, e0, e1));
         printf("hipMemcpy D2D 2 GiB: %.3f ms -> %.2f TB/s (read+write)\n", ms / 5, 2.0 * bytes * 5 / (ms * 1e-3) * 1e-12);
+    }
+    {
+        size_t bytes = (size_t)4 << 30;
+        ulonglong2 *a, *b;
+        CHK(hipMalloc(&a, bytes));
+        CHK(hipMalloc(&b, bytes));
+        CHK(hipMemset(a, 1, bytes));
+        CHK(hipMemset(b, 1, bytes));
+        hipEvent_t e0, e1;
+        CHK(hipEventCreate(&e0));
+        CHK(hipEventCreate(&e1));
+        size_t n = bytes / 16;
+        const char *names[] = { "copy 16B/lane grid 2048", "copy nontemporal grid 2048", "copy 16B/lane grid 8192",
+                                "in-place rmw 32KiB tiles, persistent 1024 WGs", "in-place rmw 32KiB tiles, one WG per tile" };
+        for (int variant = 0; variant < 5; ++variant)
+        {
+            float best = 1e9;
+            for (int rep = 0; rep < 4; ++rep)
+            {
+                CHK(hipEventRecord(e0, 0));
+                if (variant == 0) hipLaunchKernelGGL(copyk<0>, dim3(256 * 8), dim3(256), 0, 0, a, b, n);
+                if (variant == 1) hipLaunchKernelGGL(copyk<1>, dim3(256 * 8), dim3(256), 0, 0, a, b, n);
+                if (variant == 2) hipLaunchKernelGGL(copyk<0>, dim3(256 * 32), dim3(256), 0, 0, a, b, n);
+                if (variant == 3) hipLaunchKernelGGL(rmwk<1>, dim3(256 * 4), dim3(256), 0, 0, a, bytes / 32768);
+                if (variant == 4) hipLaunchKernelGGL(rmwk<1>, dim3((unsigned)(bytes / 32768)), dim3(256), 0, 0, a, bytes / 32768);
+                CHK(hipEventRecord(e1, 0));
+                CHK(hipEventSynchronize(e1));
+                float ms;
+                CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            printf("%-48s 4 GiB: %.3f ms -> %.2f TB/s (read+write)\n", names[variant], best, 2.0 * bytes / (best * 1e-3) * 1e-12);
+        }
     }
     return 0;
 }

@@ -83,4 +83,7 @@ struct moai_ctx
     // Galois permutation tables, built lazily per element (galois.cpp:18-51)
     std::vector<uint32_t *> galois_tables; // [N] entries index (elt-1)>>1, device pointers
     void *mutex = nullptr;
+    // serialises the enqueue of multi-kernel operations that share a stream's workspace arena: callers
+    // on different host threads may target the same stream (MOAI's OpenMP loops do)
+    void *op_mutex = nullptr;
 };

@@ -241,6 +241,7 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
     c->roots.resize(k);
     c->pc_host.resize(k);
     c->mutex = new std::mutex();
+    c->op_mutex = new std::mutex();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
     {
@@ -346,6 +347,7 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
         }
     }
     delete static_cast<std::mutex *>(c->mutex);
+    delete static_cast<std::mutex *>(c->op_mutex);
     delete c;
 }
 

@@ -534,6 +534,7 @@ extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size
     const size_t row_bytes = c->n * sizeof(uint64_t);
     const size_t sz_last = align256(P * row_bytes);
     const size_t sz_u = align256(P * (L - 1) * row_bytes);
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
     void *wsp;
     rc = workspace(c, sz_last + sz_u, s, &wsp);
     if (rc)
@@ -564,6 +565,7 @@ extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target
     {
         return set_error(MOAI_EINVAL, "null argument");
     }
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
     void *wsp;
     rc = workspace(c, switch_key_ws_bytes(c, L, batch), (hipStream_t)stream, &wsp);
     if (rc)
@@ -590,6 +592,7 @@ extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t
         return set_error(MOAI_EINVAL, "bad pointers");
     }
     hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
     void *wsp;
     rc = workspace(c, switch_key_ws_bytes(c, L, batch), s, &wsp);
     if (rc)
@@ -622,6 +625,7 @@ extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t g
     hipStream_t s = (hipStream_t)stream;
     const size_t row_bytes = c->n * sizeof(uint64_t);
     const size_t sz_tmp = align256(batch * 2 * L * row_bytes);
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
     void *wsp;
     rc = workspace(c, sz_tmp + switch_key_ws_bytes(c, L, batch), s, &wsp);
     if (rc)
@@ -660,6 +664,7 @@ extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, siz
     }
     hipStream_t s = (hipStream_t)stream;
     const size_t row_bytes = c->n * sizeof(uint64_t);
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
     void *wsp;
     rc = workspace(c, align256(P * row_bytes), s, &wsp);
     if (rc)

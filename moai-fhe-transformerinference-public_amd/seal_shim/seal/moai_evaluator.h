@@ -1,0 +1,863 @@
+// seal/moai_evaluator.h -- seal::Evaluator over the C ABI.  Same public methods, argument meaning and
+// exceptions as SEAL/evaluator.{h,cpp} (CKKS paths) including the fork's additions
+// (SEAL/evaluator.cpp:395-594, SEAL/evaluator.h:1296-1386).  Every method validates on the host first,
+// exactly where the reference throws, and only then enqueues device work.
+#pragma once
+
+namespace seal
+{
+    namespace util
+    {
+        // SEAL/util/common.h are_close
+        inline bool are_close(double a, double b)
+        {
+            double scale_factor = std::max({ std::fabs(a), std::fabs(b), 1.0 });
+            return std::fabs(a - b) < std::numeric_limits<double>::epsilon() * scale_factor;
+        }
+    } // namespace util
+
+    class Evaluator
+    {
+    public:
+        // the fork's constructor (SEAL/evaluator.h:84)
+        Evaluator(const SEALContext &context, CKKSEncoder &encoder) : context_(context), encoder_(encoder)
+        {}
+        Evaluator(const Evaluator &) = delete;
+        Evaluator &operator=(const Evaluator &) = delete;
+
+        // ---- negate / add / sub ------------------------------------------------------------------------
+        void negate_inplace(Ciphertext &encrypted) const
+        {
+            check_ct(encrypted, "encrypted");
+            hip(moai_negate(dev(), encrypted.device_data(), encrypted.device_data(), encrypted.size(),
+                            encrypted.coeff_modulus_size(), st()));
+        }
+        void negate(const Ciphertext &encrypted, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            negate_inplace(destination);
+        }
+        void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            addsub(encrypted1, encrypted2, false);
+        }
+        void add(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const
+        {
+            if (&encrypted2 == &destination)
+            {
+                add_inplace(destination, encrypted1);
+            }
+            else
+            {
+                destination = encrypted1;
+                add_inplace(destination, encrypted2);
+            }
+        }
+        void add_many(const std::vector<Ciphertext> &encrypteds, Ciphertext &destination) const
+        {
+            if (encrypteds.empty())
+            {
+                throw std::invalid_argument("encrypteds cannot be empty");
+            }
+            for (auto &e : encrypteds)
+            {
+                if (&e == &destination)
+                {
+                    throw std::invalid_argument("encrypteds must be different from destination");
+                }
+            }
+            destination = encrypteds[0];
+            for (std::size_t i = 1; i < encrypteds.size(); i++)
+            {
+                add_inplace(destination, encrypteds[i]);
+            }
+        }
+        void sub_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            addsub(encrypted1, encrypted2, true);
+        }
+        void sub(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const
+        {
+            if (&encrypted2 == &destination)
+            {
+                sub_inplace(destination, encrypted1);
+                negate_inplace(destination);
+            }
+            else
+            {
+                destination = encrypted1;
+                sub_inplace(destination, encrypted2);
+            }
+        }
+
+        // ---- multiply / square / relinearize -----------------------------------------------------------
+        void multiply_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2,
+                              MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            check_ct(encrypted1, "encrypted1");
+            check_ct(encrypted2, "encrypted2");
+            if (encrypted1.parms_id() != encrypted2.parms_id())
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            }
+            if (!(encrypted1.is_ntt_form() && encrypted2.is_ntt_form()))
+            {
+                throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+            }
+            if (encrypted1.size() != 2 || encrypted2.size() != 2)
+            {
+                throw std::logic_error("only size-2 by size-2 products are provided on the device");
+            }
+            auto cd = context_.get_context_data(encrypted1.parms_id());
+            double new_scale = encrypted1.scale() * encrypted2.scale();
+            if (!scale_ok(new_scale, *cd))
+            {
+                throw std::invalid_argument("scale out of bounds");
+            }
+            const std::size_t L = encrypted1.coeff_modulus_size();
+            Ciphertext out;
+            out.resize(context_, encrypted1.parms_id(), 3);
+            if (&encrypted1 == &encrypted2 || encrypted1.device_data() == encrypted2.device_data())
+            {
+                hip(moai_ct_square(dev(), encrypted1.device_data(), out.device_data(), L, 1, st()));
+            }
+            else
+            {
+                hip(moai_ct_multiply(dev(), encrypted1.device_data(), encrypted2.device_data(), out.device_data(), L, 1,
+                                     st()));
+            }
+            out.is_ntt_form() = true;
+            out.scale() = new_scale;
+            encrypted1 = std::move(out);
+        }
+        void multiply(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination,
+                      MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            if (&encrypted2 == &destination)
+            {
+                multiply_inplace(destination, encrypted1);
+            }
+            else
+            {
+                destination = encrypted1;
+                multiply_inplace(destination, encrypted2);
+            }
+        }
+        void square_inplace(Ciphertext &encrypted, MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            multiply_inplace(encrypted, encrypted);
+        }
+        void square(const Ciphertext &encrypted, Ciphertext &destination, MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            square_inplace(destination);
+        }
+        void relinearize_inplace(Ciphertext &encrypted, const RelinKeys &relin_keys,
+                                 MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // SEAL/evaluator.cpp:1345-1400
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            if (!cd)
+            {
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            }
+            if (relin_keys.parms_id() != context_.key_parms_id())
+            {
+                throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+            }
+            if (encrypted.size() == 2)
+            {
+                return;
+            }
+            if (encrypted.size() != 3)
+            {
+                throw std::logic_error("only size-3 ciphertexts can be relinearized on the device");
+            }
+            if (relin_keys.size() < 1)
+            {
+                throw std::invalid_argument("not enough relinearization keys");
+            }
+            if (!encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            }
+            const std::size_t L = encrypted.coeff_modulus_size();
+            Ciphertext out;
+            out.resize(context_, encrypted.parms_id(), 2);
+            hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0), out.device_data(), L, 1, st()));
+            out.is_ntt_form() = true;
+            out.scale() = encrypted.scale();
+            encrypted = std::move(out);
+        }
+        void relinearize(const Ciphertext &encrypted, const RelinKeys &relin_keys, Ciphertext &destination,
+                         MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            relinearize_inplace(destination, relin_keys);
+        }
+
+        // ---- modulus switching / rescaling ---------------------------------------------------------------
+        void mod_switch_to_next(const Ciphertext &encrypted, Ciphertext &destination,
+                                MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            drop_levels(encrypted, destination, 1);
+        }
+        void mod_switch_to_next_inplace(Ciphertext &encrypted, MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            Ciphertext out;
+            drop_levels(encrypted, out, 1);
+            encrypted = std::move(out);
+        }
+        void mod_switch_to_next_inplace(Plaintext &plain) const
+        {
+            auto cd = context_.get_context_data(plain.parms_id());
+            if (!cd || !plain.is_ntt_form())
+            {
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+            }
+            auto next = cd->next_context_data();
+            if (!next)
+            {
+                throw std::invalid_argument("end of modulus switching chain reached");
+            }
+            drop_plain(plain, *next);
+        }
+        void mod_switch_to_next(const Plaintext &plain, Plaintext &destination) const
+        {
+            destination = plain;
+            mod_switch_to_next_inplace(destination);
+        }
+        void mod_switch_to_inplace(Ciphertext &encrypted, parms_id_type parms_id,
+                                   MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // SEAL/evaluator.cpp:1630-1658; the level-by-level loop becomes one k-level drop
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            auto target = context_.get_context_data(parms_id);
+            if (!cd)
+            {
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            }
+            if (!target)
+            {
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            }
+            if (cd->chain_index() < target->chain_index())
+            {
+                throw std::invalid_argument("cannot switch to higher level modulus");
+            }
+            std::size_t drop = cd->chain_index() - target->chain_index();
+            if (drop == 0)
+            {
+                return;
+            }
+            Ciphertext out;
+            drop_levels(encrypted, out, drop);
+            encrypted = std::move(out);
+        }
+        void mod_switch_to(const Ciphertext &encrypted, parms_id_type parms_id, Ciphertext &destination,
+                           MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            mod_switch_to_inplace(destination, parms_id);
+        }
+        void mod_switch_to_inplace(Plaintext &plain, parms_id_type parms_id) const
+        {
+            auto cd = context_.get_context_data(plain.parms_id());
+            auto target = context_.get_context_data(parms_id);
+            if (!cd || !plain.is_ntt_form())
+            {
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+            }
+            if (!target)
+            {
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            }
+            if (cd->chain_index() < target->chain_index())
+            {
+                throw std::invalid_argument("cannot switch to higher level modulus");
+            }
+            if (cd->chain_index() != target->chain_index())
+            {
+                drop_plain(plain, *target);
+            }
+        }
+        void mod_switch_to(const Plaintext &plain, parms_id_type parms_id, Plaintext &destination) const
+        {
+            destination = plain;
+            mod_switch_to_inplace(destination, parms_id);
+        }
+        void rescale_to_next(const Ciphertext &encrypted, Ciphertext &destination,
+                             MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // SEAL/evaluator.cpp:1682-1720 / :1402-1481
+            check_ct(encrypted, "encrypted");
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            if (context_.last_parms_id() == encrypted.parms_id())
+            {
+                throw std::invalid_argument("end of modulus switching chain reached");
+            }
+            if (!encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            }
+            auto next = cd->next_context_data();
+            const std::size_t L = encrypted.coeff_modulus_size();
+            Ciphertext out;
+            out.resize(context_, next->parms_id(), encrypted.size());
+            hip(moai_rescale(dev(), encrypted.device_data(), out.device_data(), encrypted.size(), L, 1, st()));
+            out.is_ntt_form() = true;
+            out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus().back().value());
+            destination = std::move(out);
+        }
+        void rescale_to_next_inplace(Ciphertext &encrypted, MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            Ciphertext out;
+            rescale_to_next(encrypted, out);
+            encrypted = std::move(out);
+        }
+        void rescale_to_inplace(Ciphertext &encrypted, parms_id_type parms_id,
+                                MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            auto target = context_.get_context_data(parms_id);
+            if (!cd)
+            {
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            }
+            if (!target)
+            {
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            }
+            if (cd->chain_index() < target->chain_index())
+            {
+                throw std::invalid_argument("cannot switch to higher level modulus");
+            }
+            while (encrypted.parms_id() != parms_id)
+            {
+                rescale_to_next_inplace(encrypted);
+            }
+        }
+        void rescale_to(const Ciphertext &encrypted, parms_id_type parms_id, Ciphertext &destination,
+                        MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            rescale_to_inplace(destination, parms_id);
+        }
+
+        // ---- plaintext operations ----------------------------------------------------------------------------
+        void add_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const
+        {
+            plain_addsub(encrypted, plain, false);
+        }
+        void add_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            add_plain_inplace(destination, plain);
+        }
+        void sub_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const
+        {
+            plain_addsub(encrypted, plain, true);
+        }
+        void sub_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            sub_plain_inplace(destination, plain);
+        }
+        void multiply_plain_inplace(Ciphertext &encrypted, const Plaintext &plain,
+                                    MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // SEAL/evaluator.cpp:2154-2198 -> multiply_plain_ntt :2336-2373
+            check_ct(encrypted, "encrypted");
+            if (!plain.is_ntt_form() || !encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("NTT form mismatch");
+            }
+            if (encrypted.parms_id() != plain.parms_id())
+            {
+                throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+            }
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            double new_scale = encrypted.scale() * plain.scale();
+            if (!scale_ok(new_scale, *cd))
+            {
+                throw std::invalid_argument("scale out of bounds");
+            }
+            const std::size_t L = encrypted.coeff_modulus_size();
+            if (plain.is_scalar())
+            {
+                hip(moai_mul_scalar_rows(dev(), encrypted.device_data(), plain.scalar_rows().data(), encrypted.device_data(),
+                                         encrypted.size(), L, st()));
+            }
+            else
+            {
+                hip(moai_dyadic_mul(dev(), encrypted.device_data(), plain.device_data(), encrypted.device_data(),
+                                    encrypted.size(), 1, L, st()));
+            }
+            encrypted.scale() = new_scale;
+        }
+        void multiply_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination,
+                            MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            multiply_plain_inplace(destination, plain);
+        }
+
+        // ---- NTT form ---------------------------------------------------------------------------------------------
+        void transform_to_ntt_inplace(Ciphertext &encrypted) const
+        {
+            check_ct(encrypted, "encrypted");
+            if (encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("encrypted is already in NTT form");
+            }
+            hip(moai_ntt_forward(dev(), encrypted.device_data(), encrypted.size(), encrypted.coeff_modulus_size(), nullptr,
+                                 st()));
+            encrypted.is_ntt_form() = true;
+        }
+        void transform_to_ntt(const Ciphertext &encrypted, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            transform_to_ntt_inplace(destination);
+        }
+        void transform_from_ntt_inplace(Ciphertext &encrypted) const
+        {
+            check_ct(encrypted, "encrypted");
+            if (!encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("encrypted_ntt is not in NTT form");
+            }
+            hip(moai_ntt_inverse(dev(), encrypted.device_data(), encrypted.size(), encrypted.coeff_modulus_size(), nullptr,
+                                 st()));
+            encrypted.is_ntt_form() = false;
+        }
+        void transform_from_ntt(const Ciphertext &encrypted, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            transform_from_ntt_inplace(destination);
+        }
+
+        // ---- Galois / rotations ---------------------------------------------------------------------------------
+        void apply_galois_inplace(Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
+                                  MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // SEAL/evaluator.cpp:2563-2665
+            check_ct(encrypted, "encrypted");
+            if (galois_keys.parms_id() != context_.key_parms_id())
+            {
+                throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+            }
+            if (!(galois_elt & 1) || galois_elt >= 2 * context_.n())
+            {
+                throw std::invalid_argument("Galois element is not valid");
+            }
+            if (encrypted.size() > 2)
+            {
+                throw std::invalid_argument("encrypted size must be 2");
+            }
+            if (!galois_keys.has_key(galois_elt))
+            {
+                throw std::invalid_argument("Galois key not present");
+            }
+            if (!encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            }
+            hip(moai_apply_galois(dev(), encrypted.device_data(), encrypted.coeff_modulus_size(), galois_elt,
+                                  galois_keys.device_key(GaloisKeys::get_index(galois_elt)), 1, st()));
+        }
+        void apply_galois(const Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
+                          Ciphertext &destination, MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            apply_galois_inplace(destination, galois_elt, galois_keys);
+        }
+        void rotate_vector_inplace(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys,
+                                   MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            rotate_internal(encrypted, steps, galois_keys);
+        }
+        void rotate_vector(const Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys, Ciphertext &destination,
+                           MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            rotate_vector_inplace(destination, steps, galois_keys);
+        }
+        void complex_conjugate_inplace(Ciphertext &encrypted, const GaloisKeys &galois_keys,
+                                       MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // conjugate_internal, SEAL/evaluator.h:1428-1450: Galois element 2N - 1
+            apply_galois_inplace(encrypted, static_cast<std::uint32_t>(2 * context_.n() - 1), galois_keys);
+        }
+        void complex_conjugate(const Ciphertext &encrypted, const GaloisKeys &galois_keys, Ciphertext &destination,
+                               MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            destination = encrypted;
+            complex_conjugate_inplace(destination, galois_keys);
+        }
+
+        // ---- fork additions (SEAL/evaluator.cpp:395-594) -------------------------------------------------------
+        void add_const_inplace(Ciphertext &encrypted, double value) const
+        {
+            Plaintext const_plain;
+            encoder_.encode(value, encrypted.scale(), const_plain);
+            mod_switch_to_inplace(const_plain, encrypted.parms_id());
+            add_plain_inplace(encrypted, const_plain);
+        }
+        void add_const(const Ciphertext &encrypted, double value, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            add_const_inplace(destination, value);
+        }
+        void multiply_const_inplace(Ciphertext &encrypted, double value) const
+        {
+            Plaintext const_plain;
+            encoder_.encode(value, encrypted.scale(), const_plain);
+            mod_switch_to_inplace(const_plain, encrypted.parms_id());
+            multiply_plain_inplace(encrypted, const_plain);
+        }
+        void multiply_const(const Ciphertext &encrypted, double value, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            multiply_const_inplace(destination, value);
+        }
+        template <typename T>
+        void multiply_vector_inplace(Ciphertext &encrypted, const std::vector<T> &value) const
+        {
+            Plaintext vector_plain;
+            encoder_.encode(value, encrypted.scale(), vector_plain);
+            mod_switch_to_inplace(vector_plain, encrypted.parms_id());
+            multiply_plain_inplace(encrypted, vector_plain);
+        }
+        template <typename T>
+        void multiply_vector(const Ciphertext &encrypted, const std::vector<T> &value, Ciphertext &destination) const
+        {
+            destination = encrypted;
+            multiply_vector_inplace(destination, value);
+        }
+        // SEAL/evaluator.h:1371-1378
+        template <typename T>
+        void multiply_vector_inplace_reduced_error(Ciphertext &encrypted, const std::vector<T> &value) const
+        {
+            Plaintext plain;
+            encoder_.encode(value, encrypted.scale(), plain);
+            mod_switch_to_inplace(plain, encrypted.parms_id());
+            multiply_plain_inplace(encrypted, plain);
+        }
+        template <typename T>
+        void multiply_vector_reduced_error(const Ciphertext &encrypted, const std::vector<T> &value,
+                                           Ciphertext &destination) const
+        {
+            destination = encrypted;
+            multiply_vector_inplace_reduced_error(destination, value);
+        }
+        void double_inplace(Ciphertext &encrypted) const
+        {
+            add_inplace(encrypted, encrypted);
+        }
+        void add_inplace_reduced_error(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            reduced_error(encrypted1, encrypted2, nullptr, 0);
+        }
+        void add_reduced_error(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const
+        {
+            destination = encrypted1;
+            add_inplace_reduced_error(destination, encrypted2);
+        }
+        void sub_inplace_reduced_error(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
+        {
+            reduced_error(encrypted1, encrypted2, nullptr, 1);
+        }
+        void sub_reduced_error(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const
+        {
+            destination = encrypted1;
+            sub_inplace_reduced_error(destination, encrypted2);
+        }
+        void multiply_inplace_reduced_error(Ciphertext &encrypted1, const Ciphertext &encrypted2,
+                                            const RelinKeys &relin_keys) const
+        {
+            reduced_error(encrypted1, encrypted2, &relin_keys, 2);
+        }
+        void multiply_reduced_error(const Ciphertext &encrypted1, const Ciphertext &encrypted2, const RelinKeys &relin_keys,
+                                    Ciphertext &destination) const
+        {
+            destination = encrypted1;
+            multiply_inplace_reduced_error(destination, encrypted2, relin_keys);
+        }
+
+    private:
+        moai_ctx *dev() const
+        {
+            return context_.device();
+        }
+        void *st() const
+        {
+            return context_.stream();
+        }
+        static void hip(int rc)
+        {
+            util::hip_check(rc);
+        }
+        static bool scale_ok(double scale, const SEALContext::ContextData &cd)
+        {
+            // is_scale_within_bounds, SEAL/evaluator.cpp:29-48
+            int bound = cd.total_coeff_modulus_bit_count();
+            return !(scale <= 0 || (static_cast<int>(std::log2(scale)) >= bound));
+        }
+        void check_ct(const Ciphertext &c, const char *name) const
+        {
+            if (!context_.get_context_data(c.parms_id()) || c.size() < 2 || !c.device_data())
+            {
+                throw std::invalid_argument(std::string(name) + " is not valid for encryption parameters");
+            }
+        }
+
+        // SEAL/evaluator.cpp:155-240 / :263-350
+        void addsub(Ciphertext &e1, const Ciphertext &e2, bool sub) const
+        {
+            check_ct(e1, "encrypted1");
+            check_ct(e2, "encrypted2");
+            if (e1.parms_id() != e2.parms_id())
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            }
+            if (e1.is_ntt_form() != e2.is_ntt_form())
+            {
+                throw std::invalid_argument("NTT form mismatch");
+            }
+            if (!util::are_close(e1.scale(), e2.scale()))
+            {
+                throw std::invalid_argument("scale mismatch");
+            }
+            const std::size_t L = e1.coeff_modulus_size(), n = e1.poly_modulus_degree();
+            const std::size_t min_size = std::min(e1.size(), e2.size());
+            const std::size_t max_size = std::max(e1.size(), e2.size());
+            if (e1.size() < max_size)
+            {
+                // grow encrypted1, keeping its polynomials
+                Ciphertext grown;
+                grown.resize(context_, e1.parms_id(), max_size);
+                hip(moai_memcpy_d2d(grown.device_data(), e1.device_data(), e1.size() * L * n * 8, st()));
+                grown.is_ntt_form() = e1.is_ntt_form();
+                grown.scale() = e1.scale();
+                e1 = std::move(grown);
+            }
+            if (sub)
+            {
+                hip(moai_sub(dev(), e1.device_data(), e2.device_data(), e1.device_data(), min_size, L, st()));
+            }
+            else
+            {
+                hip(moai_add(dev(), e1.device_data(), e2.device_data(), e1.device_data(), min_size, L, st()));
+            }
+            if (e2.size() > min_size)
+            {
+                // copy (add) or negate (sub) the remaining polynomials of encrypted2
+                std::uint64_t *dst = e1.device_data() + min_size * L * n;
+                const std::uint64_t *src = e2.device_data() + min_size * L * n;
+                if (sub)
+                {
+                    hip(moai_negate(dev(), src, dst, e2.size() - min_size, L, st()));
+                }
+                else
+                {
+                    hip(moai_memcpy_d2d(dst, src, (e2.size() - min_size) * L * n * 8, st()));
+                }
+            }
+        }
+
+        // SEAL/evaluator.cpp:1938-2044 / :2046-2152: touches polynomial 0 only
+        void plain_addsub(Ciphertext &encrypted, const Plaintext &plain, bool sub) const
+        {
+            check_ct(encrypted, "encrypted");
+            if (!encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            }
+            if (!plain.is_ntt_form())
+            {
+                throw std::invalid_argument("plain must be in NTT form");
+            }
+            if (encrypted.parms_id() != plain.parms_id())
+            {
+                throw std::invalid_argument("encrypted and plain parameter mismatch");
+            }
+            if (!util::are_close(encrypted.scale(), plain.scale()))
+            {
+                throw std::invalid_argument("scale mismatch");
+            }
+            const std::size_t L = encrypted.coeff_modulus_size();
+            if (plain.is_scalar())
+            {
+                std::vector<std::uint64_t> s = plain.scalar_rows();
+                if (sub)
+                {
+                    auto cd = context_.get_context_data(encrypted.parms_id());
+                    const auto &cm = cd->parms().coeff_modulus();
+                    for (std::size_t r = 0; r < L; r++)
+                    {
+                        s[r] = s[r] ? cm[r].value() - s[r] : 0;
+                    }
+                }
+                hip(moai_add_scalar_rows(dev(), encrypted.device_data(), s.data(), encrypted.device_data(), 1, L, st()));
+            }
+            else if (sub)
+            {
+                hip(moai_sub(dev(), encrypted.device_data(), plain.device_data(), encrypted.device_data(), 1, L, st()));
+            }
+            else
+            {
+                hip(moai_add(dev(), encrypted.device_data(), plain.device_data(), encrypted.device_data(), 1, L, st()));
+            }
+        }
+
+        // SEAL/evaluator.cpp:1483-1546 applied `drop` times in one strided copy
+        void drop_levels(const Ciphertext &encrypted, Ciphertext &destination, std::size_t drop) const
+        {
+            check_ct(encrypted, "encrypted");
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            if (cd->chain_index() < drop)
+            {
+                throw std::invalid_argument("end of modulus switching chain reached");
+            }
+            if (!encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            }
+            const std::size_t L = encrypted.coeff_modulus_size();
+            auto target = context_.data_level(L - drop);
+            Ciphertext out;
+            out.resize(context_, target->parms_id(), encrypted.size());
+            hip(moai_mod_drop(dev(), encrypted.device_data(), out.device_data(), encrypted.size(), L, drop, 1, st()));
+            out.is_ntt_form() = true;
+            out.scale() = encrypted.scale();
+            destination = std::move(out);
+        }
+
+        // SEAL/evaluator.cpp:1548-1581: a CKKS plaintext just loses its trailing rows
+        void drop_plain(Plaintext &plain, const SEALContext::ContextData &target) const
+        {
+            const std::size_t L = target.parms().coeff_modulus().size();
+            if (plain.is_scalar())
+            {
+                plain.scalar_rows_.resize(L);
+            }
+            plain.L_ = L;
+            plain.parms_id_ = target.parms_id();
+        }
+
+        // SEAL/evaluator.cpp:2667-2722
+        void rotate_internal(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
+        {
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            if (!cd)
+            {
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            }
+            if (galois_keys.parms_id() != context_.key_parms_id())
+            {
+                throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+            }
+            if (steps == 0)
+            {
+                return;
+            }
+            const std::size_t n = context_.n();
+            std::uint32_t elt = moai_galois_elt_from_step(dev(), steps);
+            if (!elt)
+            {
+                throw std::invalid_argument("step count too large");
+            }
+            if (galois_keys.has_key(elt))
+            {
+                apply_galois_inplace(encrypted, elt, galois_keys);
+                return;
+            }
+            // decompose into power-of-two rotations (non-adjacent form)
+            std::vector<int> naf_steps = util::naf(steps);
+            if (naf_steps.size() == 1)
+            {
+                throw std::invalid_argument("Galois key not present");
+            }
+            for (int s : naf_steps)
+            {
+                if (static_cast<std::size_t>(std::abs(s)) != (n >> 1))
+                {
+                    rotate_internal(encrypted, s, galois_keys);
+                }
+            }
+        }
+
+        // the three *_reduced_error compositions (Kim et al., CT-RSA'22), SEAL/evaluator.cpp:419-592
+        void reduced_error(Ciphertext &encrypted1, const Ciphertext &encrypted2, const RelinKeys *relin_keys, int op) const
+        {
+            const std::size_t c1 = encrypted1.coeff_modulus_size();
+            const std::size_t c2 = encrypted2.coeff_modulus_size();
+            auto combine = [&](Ciphertext &a, const Ciphertext &b) {
+                if (op == 0)
+                {
+                    add_inplace(a, b);
+                }
+                else if (op == 1)
+                {
+                    sub_inplace(a, b);
+                }
+                else
+                {
+                    multiply_inplace(a, b);
+                }
+            };
+            if (c1 == c2)
+            {
+                encrypted1.scale() = encrypted2.scale();
+                combine(encrypted1, encrypted2);
+                if (op == 2)
+                {
+                    relinearize_inplace(encrypted1, *relin_keys);
+                }
+                return;
+            }
+            if (c1 < c2)
+            {
+                auto cd = context_.get_context_data(encrypted2.parms_id());
+                if (!cd)
+                {
+                    throw std::invalid_argument("encrypted2 is not valid for encryption parameters");
+                }
+                double q_last = static_cast<double>(cd->parms().coeff_modulus()[c2 - 1].value());
+                Ciphertext adjusted;
+                double scale_adjust = encrypted1.scale() * q_last / (encrypted2.scale() * encrypted2.scale());
+                multiply_const(encrypted2, scale_adjust, adjusted);
+                adjusted.scale() = encrypted1.scale() * q_last;
+                rescale_to_next_inplace(adjusted);
+                mod_switch_to_inplace(adjusted, encrypted1.parms_id());
+                encrypted1.scale() = adjusted.scale();
+                combine(encrypted1, adjusted);
+            }
+            else
+            {
+                auto cd = context_.get_context_data(encrypted1.parms_id());
+                if (!cd)
+                {
+                    throw std::invalid_argument("encrypted1 is not valid for encryption parameters");
+                }
+                double q_last = static_cast<double>(cd->parms().coeff_modulus()[c1 - 1].value());
+                Ciphertext adjusted;
+                double scale_adjust = encrypted2.scale() * q_last / (encrypted1.scale() * encrypted1.scale());
+                multiply_const(encrypted1, scale_adjust, adjusted);
+                adjusted.scale() = encrypted2.scale() * q_last;
+                rescale_to_next_inplace(adjusted);
+                mod_switch_to_inplace(adjusted, encrypted2.parms_id());
+                adjusted.scale() = encrypted2.scale();
+                combine(adjusted, encrypted2);
+                encrypted1 = std::move(adjusted);
+            }
+            if (op == 2)
+            {
+                relinearize_inplace(encrypted1, *relin_keys);
+            }
+        }
+
+        SEALContext context_;
+        CKKSEncoder &encoder_;
+    };
+} // namespace seal

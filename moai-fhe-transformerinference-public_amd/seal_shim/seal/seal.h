@@ -1,0 +1,1059 @@
+// seal/seal.h -- the seal:: C++ API surface MOAI consumes (include/include.hpp:10), re-provided over
+// the C ABI of libmoai_hip.so (include/moai_hip.h).  MOAI's headers compile against this file
+// unchanged; every ciphertext operation is validated on the host exactly where the reference
+// validates it (same exception types and messages) and then enqueued as hand-written HIP kernels.
+//
+// Mirrors (names, argument meaning, error behaviour), SEAL/ = thirdparty/SEAL-4.1-bs/native/src/seal/:
+//   EncryptionParameters  SEAL/encryptionparams.h (fork: set_secret_key_hamming_weight :188-200,
+//                         set_sparse_slots :217-234)
+//   Modulus, CoeffModulus SEAL/modulus.{h,cpp}
+//   SEALContext           SEAL/context.{h,cpp} (modulus switching chain :422-522)
+//   Plaintext, Ciphertext SEAL/plaintext.h, SEAL/ciphertext.h (layout [poly][prime][coeff] :337-349)
+//   KSwitchKeys/RelinKeys/GaloisKeys  SEAL/kswitchkeys.h:340, relinkeys.h:58, galoiskeys.h:48
+//   KeyGenerator, Encryptor, Decryptor  SEAL/keygenerator.cpp, encryptor.cpp, decryptor.cpp (client side)
+//   CKKSEncoder           SEAL/ckks.{h,cpp}
+//   Evaluator             SEAL/evaluator.{h,cpp} incl. the fork's additions :395-594
+//
+// Residues live in device memory; metadata lives on the host.  All work is enqueued on the context's
+// stream in host call order, so results are ordered exactly as the calling program orders them, also
+// when MOAI calls from many OpenMP threads.  Client-side pieces (keygen, encrypt, decrypt, encoder
+// FFT) are host code and out of the hot-path scope; their NTTs still run on the device.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "moai_hip.h"
+
+namespace seal
+{
+    using parms_id_type = std::array<std::uint64_t, 4>;
+    static const parms_id_type parms_id_zero = { 0, 0, 0, 0 };
+
+    enum class scheme_type : std::uint8_t
+    {
+        none = 0x0,
+        bfv = 0x1,
+        ckks = 0x2,
+        bgv = 0x3
+    };
+
+    enum class sec_level_type : int
+    {
+        none = 0,
+        tc128 = 128,
+        tc192 = 192,
+        tc256 = 256
+    };
+
+    // ---- memory pool handles: accepted and ignored (device memory comes from the moai arena) --------
+    class MemoryPoolHandle
+    {
+    public:
+        MemoryPoolHandle() = default;
+        explicit operator bool() const noexcept
+        {
+            return true;
+        }
+        static MemoryPoolHandle Global()
+        {
+            return MemoryPoolHandle();
+        }
+        static MemoryPoolHandle New(bool = false)
+        {
+            return MemoryPoolHandle();
+        }
+    };
+
+    enum class mm_prof_opt : std::uint64_t
+    {
+        mm_default = 0x0,
+        mm_force_global = 0x1,
+        mm_force_new = 0x2,
+        mm_force_thread_local = 0x4
+    };
+
+    class MemoryManager
+    {
+    public:
+        template <typename... Args>
+        static MemoryPoolHandle GetPool(Args &&...)
+        {
+            return MemoryPoolHandle();
+        }
+    };
+
+    namespace util
+    {
+        typedef unsigned __int128 u128;
+
+        inline void hip_check(int rc)
+        {
+            if (rc == MOAI_OK)
+            {
+                return;
+            }
+            std::string msg = moai_last_error();
+            switch (rc)
+            {
+            case MOAI_EINVAL:
+                throw std::invalid_argument(msg);
+            case MOAI_ERANGE:
+                throw std::out_of_range(msg);
+            case MOAI_ELOGIC:
+                throw std::logic_error(msg);
+            default:
+                throw std::runtime_error(msg);
+            }
+        }
+
+        inline int get_significant_bit_count(std::uint64_t v)
+        {
+            int n = 0;
+            while (v)
+            {
+                n++;
+                v >>= 1;
+            }
+            return n;
+        }
+
+        inline std::uint64_t mulmod(std::uint64_t a, std::uint64_t b, std::uint64_t q)
+        {
+            return static_cast<std::uint64_t>((static_cast<u128>(a) * b) % q);
+        }
+
+        inline std::uint64_t powmod(std::uint64_t a, std::uint64_t e, std::uint64_t q)
+        {
+            std::uint64_t r = 1;
+            a %= q;
+            while (e)
+            {
+                if (e & 1)
+                {
+                    r = mulmod(r, a, q);
+                }
+                a = mulmod(a, a, q);
+                e >>= 1;
+            }
+            return r;
+        }
+
+        inline bool is_prime(std::uint64_t n)
+        {
+            static const std::uint64_t bases[] = { 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37 };
+            if (n < 2)
+            {
+                return false;
+            }
+            for (std::uint64_t p : bases)
+            {
+                if (n % p == 0)
+                {
+                    return n == p;
+                }
+            }
+            std::uint64_t d = n - 1;
+            int r = 0;
+            while (!(d & 1))
+            {
+                d >>= 1;
+                r++;
+            }
+            for (std::uint64_t a : bases)
+            {
+                std::uint64_t x = powmod(a, d, n);
+                if (x == 1 || x == n - 1)
+                {
+                    continue;
+                }
+                bool composite = true;
+                for (int i = 1; i < r; i++)
+                {
+                    x = mulmod(x, x, n);
+                    if (x == n - 1)
+                    {
+                        composite = false;
+                        break;
+                    }
+                }
+                if (composite)
+                {
+                    return false;
+                }
+            }
+            return true;
+        }
+
+        inline std::uint32_t reverse_bits(std::uint32_t x, int bits)
+        {
+            std::uint32_t r = 0;
+            for (int i = 0; i < bits; i++)
+            {
+                r = (r << 1) | ((x >> i) & 1u);
+            }
+            return r;
+        }
+
+        // non-adjacent form (SEAL/util/numth.h:22-41)
+        inline std::vector<int> naf(int value)
+        {
+            std::vector<int> res;
+            bool sign = value < 0;
+            value = std::abs(value);
+            for (int i = 0; value; i++)
+            {
+                int zi = (value & 1) ? 2 - (value & 3) : 0;
+                value = (value - zi) >> 1;
+                if (zi)
+                {
+                    res.push_back((sign ? -zi : zi) * (1 << i));
+                }
+            }
+            return res;
+        }
+
+        // RAII device buffer of uint64 words
+        class DeviceArray
+        {
+        public:
+            DeviceArray() = default;
+            explicit DeviceArray(std::size_t words)
+            {
+                resize(words);
+            }
+            ~DeviceArray()
+            {
+                release();
+            }
+            DeviceArray(const DeviceArray &o) = delete;
+            DeviceArray &operator=(const DeviceArray &o) = delete;
+            DeviceArray(DeviceArray &&o) noexcept : ptr_(o.ptr_), words_(o.words_), cap_(o.cap_)
+            {
+                o.ptr_ = nullptr;
+                o.words_ = o.cap_ = 0;
+            }
+            DeviceArray &operator=(DeviceArray &&o) noexcept
+            {
+                if (this != &o)
+                {
+                    release();
+                    ptr_ = o.ptr_;
+                    words_ = o.words_;
+                    cap_ = o.cap_;
+                    o.ptr_ = nullptr;
+                    o.words_ = o.cap_ = 0;
+                }
+                return *this;
+            }
+            void release()
+            {
+                if (ptr_)
+                {
+                    moai_free(ptr_);
+                }
+                ptr_ = nullptr;
+                words_ = cap_ = 0;
+            }
+            // keeps the leading words (like DynArray::resize, SEAL/dynarray.h)
+            void resize(std::size_t words, void *stream = nullptr)
+            {
+                if (words <= cap_)
+                {
+                    words_ = words;
+                    return;
+                }
+                void *p = nullptr;
+                hip_check(moai_malloc(&p, words * sizeof(std::uint64_t)));
+                if (ptr_ && words_)
+                {
+                    hip_check(moai_memcpy_d2d(p, ptr_, words_ * sizeof(std::uint64_t), stream));
+                    // the old block may only be freed once the copy has run
+                    hip_check(moai_stream_sync(stream));
+                }
+                if (ptr_)
+                {
+                    moai_free(ptr_);
+                }
+                ptr_ = static_cast<std::uint64_t *>(p);
+                words_ = cap_ = words;
+            }
+            std::uint64_t *get() const
+            {
+                return ptr_;
+            }
+            std::size_t size() const
+            {
+                return words_;
+            }
+
+        private:
+            std::uint64_t *ptr_ = nullptr;
+            std::size_t words_ = 0;
+            std::size_t cap_ = 0;
+        };
+    } // namespace util
+
+    // =================================================================================================
+    // Modulus / CoeffModulus  (SEAL/modulus.{h,cpp})
+    // =================================================================================================
+    class Modulus
+    {
+    public:
+        Modulus(std::uint64_t value = 0)
+        {
+            set_value(value);
+        }
+        Modulus &operator=(std::uint64_t value)
+        {
+            set_value(value);
+            return *this;
+        }
+        std::uint64_t value() const noexcept
+        {
+            return value_;
+        }
+        int bit_count() const noexcept
+        {
+            return bit_count_;
+        }
+        bool is_zero() const noexcept
+        {
+            return value_ == 0;
+        }
+        bool is_prime() const noexcept
+        {
+            return util::is_prime(value_);
+        }
+        bool operator==(const Modulus &o) const noexcept
+        {
+            return value_ == o.value_;
+        }
+        bool operator!=(const Modulus &o) const noexcept
+        {
+            return value_ != o.value_;
+        }
+        bool operator<(const Modulus &o) const noexcept
+        {
+            return value_ < o.value_;
+        }
+
+    private:
+        void set_value(std::uint64_t value)
+        {
+            if (value != 0 && ((value >> 61) != 0 || value == 1))
+            {
+                throw std::invalid_argument("value can be at most 61-bit and cannot be 1");
+            }
+            value_ = value;
+            bit_count_ = util::get_significant_bit_count(value);
+        }
+        std::uint64_t value_ = 0;
+        int bit_count_ = 0;
+    };
+
+    class CoeffModulus
+    {
+    public:
+        // SEAL/modulus.cpp:142-183: primes = 1 mod 2N, found descending from 2^bits, handed out
+        // smallest-first within each bit size
+        static std::vector<Modulus> Create(std::size_t poly_modulus_degree, std::vector<int> bit_sizes)
+        {
+            if (poly_modulus_degree > 131072 || poly_modulus_degree < 2 ||
+                (poly_modulus_degree & (poly_modulus_degree - 1)) != 0)
+            {
+                throw std::invalid_argument("poly_modulus_degree is invalid");
+            }
+            if (bit_sizes.size() > 256)
+            {
+                throw std::invalid_argument("bit_sizes is invalid");
+            }
+            std::map<int, std::vector<std::uint64_t>> table;
+            std::map<int, std::size_t> count;
+            for (int b : bit_sizes)
+            {
+                if (b > 60 || b < 2)
+                {
+                    throw std::invalid_argument("bit_sizes is invalid");
+                }
+                ++count[b];
+            }
+            std::uint64_t factor = 2 * static_cast<std::uint64_t>(poly_modulus_degree);
+            for (auto &kv : count)
+            {
+                int bits = kv.first;
+                std::uint64_t value = ((std::uint64_t(1) << bits) - 1) / factor * factor + 1;
+                std::uint64_t lower = std::uint64_t(1) << (bits - 1);
+                std::vector<std::uint64_t> found;
+                while (found.size() < kv.second && value > lower)
+                {
+                    if (util::is_prime(value))
+                    {
+                        found.push_back(value);
+                    }
+                    value -= factor;
+                }
+                if (found.size() < kv.second)
+                {
+                    throw std::logic_error("failed to find enough qualifying primes");
+                }
+                table[bits] = found;
+            }
+            std::vector<Modulus> result;
+            for (int b : bit_sizes)
+            {
+                result.emplace_back(table[b].back());
+                table[b].pop_back();
+            }
+            return result;
+        }
+    };
+
+    // =================================================================================================
+    // EncryptionParameters  (SEAL/encryptionparams.h)
+    // =================================================================================================
+    class EncryptionParameters
+    {
+    public:
+        EncryptionParameters(scheme_type scheme = scheme_type::none) : scheme_(scheme)
+        {
+            if (scheme != scheme_type::ckks && scheme != scheme_type::none)
+            {
+                throw std::invalid_argument("unsupported scheme (this build provides CKKS only)");
+            }
+        }
+        void set_poly_modulus_degree(std::size_t n)
+        {
+            if (scheme_ == scheme_type::none && n)
+            {
+                throw std::logic_error("poly_modulus_degree is not supported for this scheme");
+            }
+            poly_modulus_degree_ = n;
+        }
+        void set_coeff_modulus(const std::vector<Modulus> &m)
+        {
+            if (scheme_ == scheme_type::none)
+            {
+                if (!m.empty())
+                {
+                    throw std::logic_error("coeff_modulus is not supported for this scheme");
+                }
+            }
+            else if (m.size() > 256 || m.size() < 1)
+            {
+                throw std::invalid_argument("coeff_modulus is invalid");
+            }
+            coeff_modulus_ = m;
+        }
+        // fork additions (sparse ternary secret, sparse slot packing)
+        void set_secret_key_hamming_weight(std::size_t hw)
+        {
+            secret_key_hamming_weight_ = hw;
+        }
+        void set_sparse_slots(std::size_t s)
+        {
+            sparse_slots_ = s;
+        }
+        scheme_type scheme() const noexcept
+        {
+            return scheme_;
+        }
+        std::size_t poly_modulus_degree() const noexcept
+        {
+            return poly_modulus_degree_;
+        }
+        const std::vector<Modulus> &coeff_modulus() const noexcept
+        {
+            return coeff_modulus_;
+        }
+        std::size_t secret_key_hamming_weight() const noexcept
+        {
+            return secret_key_hamming_weight_;
+        }
+        std::size_t sparse_slots() const noexcept
+        {
+            return sparse_slots_;
+        }
+
+    private:
+        scheme_type scheme_;
+        std::size_t poly_modulus_degree_ = 0;
+        std::vector<Modulus> coeff_modulus_;
+        std::size_t secret_key_hamming_weight_ = 0;
+        std::size_t sparse_slots_ = 0;
+    };
+
+    // =================================================================================================
+    // SEALContext  (SEAL/context.{h,cpp})
+    // =================================================================================================
+    class SEALContext
+    {
+    public:
+        class ContextData
+        {
+        public:
+            const EncryptionParameters &parms() const noexcept
+            {
+                return parms_;
+            }
+            const parms_id_type &parms_id() const noexcept
+            {
+                return parms_id_;
+            }
+            std::size_t chain_index() const noexcept
+            {
+                return chain_index_;
+            }
+            int total_coeff_modulus_bit_count() const noexcept
+            {
+                return total_bits_;
+            }
+            std::shared_ptr<const ContextData> prev_context_data() const noexcept
+            {
+                return prev_.lock();
+            }
+            std::shared_ptr<const ContextData> next_context_data() const noexcept
+            {
+                return next_;
+            }
+
+        private:
+            friend class SEALContext;
+            EncryptionParameters parms_;
+            parms_id_type parms_id_ = parms_id_zero;
+            std::size_t chain_index_ = 0;
+            int total_bits_ = 0;
+            std::weak_ptr<const ContextData> prev_;
+            std::shared_ptr<const ContextData> next_;
+        };
+
+        SEALContext(const EncryptionParameters &parms, bool expand_mod_chain = true,
+                    sec_level_type sec_level = sec_level_type::tc128)
+        {
+            (void)sec_level; // MOAI runs with sec_level_type::none (test_full_scheme.hpp:389)
+            if (parms.scheme() != scheme_type::ckks)
+            {
+                throw std::invalid_argument("only the CKKS scheme is provided");
+            }
+            const std::size_t n = parms.poly_modulus_degree();
+            int logn = 0;
+            while ((std::size_t(1) << logn) < n)
+            {
+                logn++;
+            }
+            if (n < 2 || (std::size_t(1) << logn) != n)
+            {
+                throw std::invalid_argument("poly_modulus_degree is invalid");
+            }
+            const auto &cm = parms.coeff_modulus();
+            std::vector<std::uint64_t> primes;
+            for (auto &m : cm)
+            {
+                primes.push_back(m.value());
+            }
+            impl_ = std::make_shared<Impl>();
+            impl_->logn = logn;
+            impl_->n = n;
+            moai_ctx *c = nullptr;
+            util::hip_check(moai_ctx_create(logn, primes.data(), primes.size(), 0, &c));
+            impl_->ctx = c;
+            util::hip_check(moai_stream_create(&impl_->stream));
+            const std::size_t k = cm.size();
+            // chain: key level (k primes), then data levels with k-1 ... 1 primes
+            std::shared_ptr<ContextData> prev;
+            std::size_t levels = expand_mod_chain ? k : (k > 1 ? 2 : 1);
+            for (std::size_t lvl = 0; lvl < levels; lvl++)
+            {
+                std::size_t count = k - lvl;
+                if (count < 1)
+                {
+                    break;
+                }
+                auto cd = std::make_shared<ContextData>();
+                EncryptionParameters p(parms);
+                std::vector<Modulus> sub(cm.begin(), cm.begin() + static_cast<std::ptrdiff_t>(count));
+                p.set_coeff_modulus(sub);
+                cd->parms_ = p;
+                cd->chain_index_ = count - 1;
+                int bits = 0;
+                std::uint64_t x = 0x4d4f4149ull;
+                for (auto &m : sub)
+                {
+                    bits += m.bit_count();
+                    x = (x ^ m.value()) * 0x9E3779B97F4A7C15ull;
+                }
+                cd->total_bits_ = bits;
+                cd->parms_id_ = { 0x4d4f41495345414cull, static_cast<std::uint64_t>(n), static_cast<std::uint64_t>(count), x };
+                if (prev)
+                {
+                    cd->prev_ = prev;
+                    prev->next_ = cd;
+                }
+                impl_->by_id[cd->parms_id_] = cd;
+                impl_->by_count[count] = cd;
+                if (lvl == 0)
+                {
+                    impl_->key = cd;
+                }
+                if ((lvl == 1) || (k == 1 && lvl == 0))
+                {
+                    impl_->first = cd;
+                }
+                impl_->last = cd;
+                prev = cd;
+            }
+            if (!impl_->first)
+            {
+                impl_->first = impl_->key;
+            }
+        }
+
+        std::shared_ptr<const ContextData> get_context_data(const parms_id_type &id) const
+        {
+            auto it = impl_->by_id.find(id);
+            return it == impl_->by_id.end() ? nullptr : it->second;
+        }
+        std::shared_ptr<const ContextData> key_context_data() const
+        {
+            return impl_->key;
+        }
+        std::shared_ptr<const ContextData> first_context_data() const
+        {
+            return impl_->first;
+        }
+        std::shared_ptr<const ContextData> last_context_data() const
+        {
+            return impl_->last;
+        }
+        const parms_id_type &key_parms_id() const
+        {
+            return impl_->key->parms_id();
+        }
+        const parms_id_type &first_parms_id() const
+        {
+            return impl_->first->parms_id();
+        }
+        const parms_id_type &last_parms_id() const
+        {
+            return impl_->last->parms_id();
+        }
+        bool using_keyswitching() const
+        {
+            return impl_->key->parms().coeff_modulus().size() > 1;
+        }
+        bool parameters_set() const
+        {
+            return true;
+        }
+
+        // ---- device side (not part of the reference API) -------------------------------------------
+        moai_ctx *device() const
+        {
+            return impl_->ctx;
+        }
+        void *stream() const
+        {
+            return impl_->stream;
+        }
+        void sync() const
+        {
+            util::hip_check(moai_stream_sync(impl_->stream));
+        }
+        std::size_t n() const
+        {
+            return impl_->n;
+        }
+        int logn() const
+        {
+            return impl_->logn;
+        }
+        std::shared_ptr<const ContextData> data_level(std::size_t prime_count) const
+        {
+            auto it = impl_->by_count.find(prime_count);
+            return it == impl_->by_count.end() ? nullptr : it->second;
+        }
+
+    private:
+        struct Impl
+        {
+            moai_ctx *ctx = nullptr;
+            void *stream = nullptr;
+            int logn = 0;
+            std::size_t n = 0;
+            std::map<parms_id_type, std::shared_ptr<ContextData>> by_id;
+            std::map<std::size_t, std::shared_ptr<ContextData>> by_count;
+            std::shared_ptr<ContextData> key, first, last;
+            ~Impl()
+            {
+                if (stream)
+                {
+                    moai_stream_sync(stream);
+                    moai_stream_destroy(stream);
+                }
+                if (ctx)
+                {
+                    moai_ctx_destroy(ctx);
+                }
+            }
+        };
+        std::shared_ptr<Impl> impl_;
+    };
+
+    // =================================================================================================
+    // Plaintext / Ciphertext
+    // =================================================================================================
+    // A CKKS plaintext is kept in NTT form over the primes of its level, [L][N] on the device.  A
+    // plaintext produced by the scalar encode overloads has constant rows (SEAL/ckks.cpp:131-150); it is
+    // kept as L scalars and never materialised, so multiply_plain / add_plain become one scalar op per row.
+    class Plaintext
+    {
+    public:
+        Plaintext(MemoryPoolHandle = MemoryPoolHandle())
+        {}
+        Plaintext(const Plaintext &o)
+        {
+            *this = o;
+        }
+        Plaintext(Plaintext &&) = default;
+        Plaintext &operator=(Plaintext &&) = default;
+        Plaintext &operator=(const Plaintext &o)
+        {
+            if (this == &o)
+            {
+                return *this;
+            }
+            parms_id_ = o.parms_id_;
+            scale_ = o.scale_;
+            n_ = o.n_;
+            L_ = o.L_;
+            scalar_rows_ = o.scalar_rows_;
+            stream_ = o.stream_;
+            data_.resize(o.data_.size());
+            if (o.data_.size())
+            {
+                util::hip_check(moai_memcpy_d2d(data_.get(), o.data_.get(), o.data_.size() * 8, stream_));
+            }
+            return *this;
+        }
+        parms_id_type &parms_id() noexcept
+        {
+            return parms_id_;
+        }
+        const parms_id_type &parms_id() const noexcept
+        {
+            return parms_id_;
+        }
+        double &scale() noexcept
+        {
+            return scale_;
+        }
+        const double &scale() const noexcept
+        {
+            return scale_;
+        }
+        bool is_ntt_form() const noexcept
+        {
+            return parms_id_ != parms_id_zero;
+        }
+        std::size_t coeff_count() const noexcept
+        {
+            return n_ * L_;
+        }
+        bool is_zero() const
+        {
+            return coeff_count() == 0;
+        }
+        // ---- device side ---------------------------------------------------------------------------
+        bool is_scalar() const
+        {
+            return !scalar_rows_.empty();
+        }
+        const std::vector<std::uint64_t> &scalar_rows() const
+        {
+            return scalar_rows_;
+        }
+        std::uint64_t *device_data() const
+        {
+            return data_.get();
+        }
+        std::size_t coeff_modulus_size() const
+        {
+            return L_;
+        }
+
+    private:
+        friend class CKKSEncoder;
+        friend class Evaluator;
+        friend class Decryptor;
+        parms_id_type parms_id_ = parms_id_zero;
+        double scale_ = 1.0;
+        std::size_t n_ = 0, L_ = 0;
+        std::vector<std::uint64_t> scalar_rows_;
+        util::DeviceArray data_;
+        void *stream_ = nullptr;
+    };
+
+    class Ciphertext
+    {
+    public:
+        Ciphertext(MemoryPoolHandle = MemoryPoolHandle())
+        {}
+        explicit Ciphertext(const SEALContext &context, MemoryPoolHandle = MemoryPoolHandle())
+        {
+            resize(context, context.first_parms_id(), 2);
+        }
+        Ciphertext(const Ciphertext &o)
+        {
+            *this = o;
+        }
+        Ciphertext(Ciphertext &&) = default;
+        Ciphertext &operator=(Ciphertext &&) = default;
+        // deep copy, like SEAL/ciphertext.cpp:16-37
+        Ciphertext &operator=(const Ciphertext &o)
+        {
+            if (this == &o)
+            {
+                return *this;
+            }
+            parms_id_ = o.parms_id_;
+            is_ntt_form_ = o.is_ntt_form_;
+            size_ = o.size_;
+            n_ = o.n_;
+            L_ = o.L_;
+            scale_ = o.scale_;
+            stream_ = o.stream_;
+            data_.resize(o.size_ * o.L_ * o.n_);
+            if (data_.size())
+            {
+                util::hip_check(moai_memcpy_d2d(data_.get(), o.data_.get(), data_.size() * 8, stream_));
+            }
+            return *this;
+        }
+        void resize(const SEALContext &context, parms_id_type parms_id, std::size_t size)
+        {
+            auto cd = context.get_context_data(parms_id);
+            if (!cd)
+            {
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            }
+            if ((size < 2 && size != 0) || size > 6)
+            {
+                throw std::invalid_argument("invalid size");
+            }
+            stream_ = context.stream();
+            parms_id_ = parms_id;
+            n_ = cd->parms().poly_modulus_degree();
+            L_ = cd->parms().coeff_modulus().size();
+            size_ = size;
+            data_.resize(size_ * L_ * n_, stream_);
+        }
+        void release()
+        {
+            data_.release();
+            size_ = 0;
+            parms_id_ = parms_id_zero;
+        }
+        std::size_t size() const noexcept
+        {
+            return size_;
+        }
+        std::size_t coeff_modulus_size() const noexcept
+        {
+            return L_;
+        }
+        std::size_t poly_modulus_degree() const noexcept
+        {
+            return n_;
+        }
+        bool &is_ntt_form() noexcept
+        {
+            return is_ntt_form_;
+        }
+        bool is_ntt_form() const noexcept
+        {
+            return is_ntt_form_;
+        }
+        parms_id_type &parms_id() noexcept
+        {
+            return parms_id_;
+        }
+        const parms_id_type &parms_id() const noexcept
+        {
+            return parms_id_;
+        }
+        double &scale() noexcept
+        {
+            return scale_;
+        }
+        const double &scale() const noexcept
+        {
+            return scale_;
+        }
+        // ---- device side ---------------------------------------------------------------------------
+        std::uint64_t *device_data() const
+        {
+            return data_.get();
+        }
+        // host copy of the residues [size][L][N] (the reference exposes data(); MOAI itself only needs it
+        // inside Bootstrapper::modraise_inplace, which maps to moai_modraise)
+        std::vector<std::uint64_t> download() const
+        {
+            std::vector<std::uint64_t> h(size_ * L_ * n_);
+            if (!h.empty())
+            {
+                util::hip_check(moai_memcpy_d2h(h.data(), data_.get(), h.size() * 8, stream_));
+                util::hip_check(moai_stream_sync(stream_));
+            }
+            return h;
+        }
+        void upload(const std::vector<std::uint64_t> &h)
+        {
+            if (h.size() != size_ * L_ * n_)
+            {
+                throw std::invalid_argument("size mismatch");
+            }
+            util::hip_check(moai_memcpy_h2d(data_.get(), h.data(), h.size() * 8, stream_));
+            util::hip_check(moai_stream_sync(stream_));
+        }
+
+    private:
+        friend class Evaluator;
+        friend class Encryptor;
+        friend class Decryptor;
+        friend class KeyGenerator;
+        // metadata-only change of level / size after the device op produced the new layout
+        void set_layout(void *stream, parms_id_type id, std::size_t size, std::size_t L, std::size_t n)
+        {
+            stream_ = stream;
+            parms_id_ = id;
+            size_ = size;
+            L_ = L;
+            n_ = n;
+        }
+        parms_id_type parms_id_ = parms_id_zero;
+        bool is_ntt_form_ = false;
+        std::size_t size_ = 0, n_ = 0, L_ = 0;
+        double scale_ = 1.0;
+        util::DeviceArray data_;
+        void *stream_ = nullptr;
+    };
+
+    // =================================================================================================
+    // keys
+    // =================================================================================================
+    class SecretKey
+    {
+    public:
+        const parms_id_type &parms_id() const
+        {
+            return parms_id_;
+        }
+
+    private:
+        friend class KeyGenerator;
+        friend class Decryptor;
+        friend class Encryptor;
+        parms_id_type parms_id_ = parms_id_zero;
+        std::shared_ptr<util::DeviceArray> ntt_; // [k][N], NTT form at the key level
+    };
+
+    class PublicKey
+    {
+    public:
+        const parms_id_type &parms_id() const
+        {
+            return ct_.parms_id();
+        }
+        const Ciphertext &data() const
+        {
+            return ct_;
+        }
+
+    private:
+        friend class KeyGenerator;
+        friend class Encryptor;
+        Ciphertext ct_;
+    };
+
+    // one entry = the reference's vector<PublicKey> of k-1 size-2 key-level ciphertexts, flattened to
+    // uint64[k-1][2][k][N] on the device (SEAL/kswitchkeys.h:340)
+    class KSwitchKeys
+    {
+    public:
+        const parms_id_type &parms_id() const
+        {
+            return parms_id_;
+        }
+        parms_id_type &parms_id()
+        {
+            return parms_id_;
+        }
+        std::size_t size() const
+        {
+            std::size_t c = 0;
+            for (auto &k : keys_)
+            {
+                c += k ? 1 : 0;
+            }
+            return c;
+        }
+        const std::uint64_t *device_key(std::size_t index) const
+        {
+            return index < keys_.size() && keys_[index] ? keys_[index]->get() : nullptr;
+        }
+
+    protected:
+        friend class KeyGenerator;
+        parms_id_type parms_id_ = parms_id_zero;
+        std::vector<std::shared_ptr<util::DeviceArray>> keys_;
+    };
+
+    class RelinKeys : public KSwitchKeys
+    {
+    public:
+        static std::size_t get_index(std::size_t key_power)
+        {
+            if (key_power < 2)
+            {
+                throw std::invalid_argument("key_power cannot be less than 2");
+            }
+            return key_power - 2;
+        }
+        bool has_key(std::size_t key_power) const
+        {
+            return device_key(get_index(key_power)) != nullptr;
+        }
+    };
+
+    class GaloisKeys : public KSwitchKeys
+    {
+    public:
+        static std::size_t get_index(std::uint32_t galois_elt)
+        {
+            if (!(galois_elt & 1))
+            {
+                throw std::invalid_argument("galois_elt is not valid");
+            }
+            return (galois_elt - 1) >> 1; // SEAL/galoiskeys.h:48
+        }
+        bool has_key(std::uint32_t galois_elt) const
+        {
+            return device_key(get_index(galois_elt)) != nullptr;
+        }
+    };
+} // namespace seal
+
+#include "seal/moai_client.h"
+#include "seal/moai_evaluator.h"

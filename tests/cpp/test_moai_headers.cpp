@@ -1,0 +1,169 @@
+// test_moai_headers.cpp -- MOAI's own headers (include/source/matrix_mul/*.hpp,
+// include/source/non_linear_func/gelu_others.hpp), included UNCHANGED from the reference checkout at
+// build time, compiled against the seal:: shim and run on the GPU at reduced sizes.  The flows follow
+// the reference's drivers (include/test/matrix_mul/test_ct_pt_matrix_mul.hpp:4-147,
+// test_ct_ct_matrix_mul.hpp:4-209) and, unlike them, assert on the decrypted result.
+#include "seal/seal.h"
+
+#include <omp.h>
+#include <sys/time.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <vector>
+
+#include "Batch_encode_encrypt.hpp"
+#include "Ct_pt_matrix_mul.hpp"
+#include "Ct_ct_matrix_mul.hpp"
+#include "gelu_others.hpp"
+
+static int g_fail = 0;
+#define CHECK(cond)                                                        \
+    do                                                                     \
+    {                                                                      \
+        if (!(cond))                                                       \
+        {                                                                  \
+            g_fail++;                                                      \
+            printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                                  \
+    } while (0)
+
+int main()
+{
+    omp_set_num_threads(4);
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t n = 4096;
+    parms.set_poly_modulus_degree(n);
+    vector<int> bits{ 60 };
+    for (int i = 0; i < 11; i++)
+    {
+        bits.push_back(40);
+    }
+    bits.push_back(60);
+    parms.set_coeff_modulus(CoeffModulus::Create(n, bits));
+    parms.set_secret_key_hamming_weight(64);
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    SecretKey sk = keygen.secret_key();
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    RelinKeys relin_keys;
+    keygen.create_relin_keys(relin_keys);
+    GaloisKeys gal_keys;
+    keygen.create_galois_keys(gal_keys);
+    CKKSEncoder encoder(context);
+    Decryptor decryptor(context, sk);
+    Evaluator evaluator(context, encoder);
+    const double scale = pow(2.0, 40);
+    const size_t slots = encoder.slot_count();
+
+    // ---- batch_input + ct_pt_matrix_mul_wo_pre ------------------------------------------------------
+    const int num_X = 4, num_row = 8, num_col = 6, col_W = 3;
+    vector<vector<vector<double>>> X(num_X, vector<vector<double>>(num_row, vector<double>(num_col)));
+    for (int j = 0; j < num_X; j++)
+        for (int k = 0; k < num_row; k++)
+            for (int i = 0; i < num_col; i++)
+                X[j][k][i] = 0.1 * (j + 1) + 0.01 * k - 0.05 * i;
+    vector<vector<double>> W(num_col, vector<double>(col_W));
+    for (int r = 0; r < num_col; r++)
+        for (int c = 0; c < col_W; c++)
+            W[r][c] = 0.25 * (r - 2) + 0.125 * c;
+    vector<Ciphertext> enc_X = batch_input(X, num_X, num_row, num_col, scale, context, pk);
+    CHECK(enc_X.size() == (size_t)num_col);
+    vector<Ciphertext> Y = ct_pt_matrix_mul_wo_pre(enc_X, W, num_col, col_W, num_col, context);
+    CHECK(Y.size() == (size_t)col_W);
+    for (int c = 0; c < col_W; c++)
+    {
+        Plaintext p;
+        vector<double> out;
+        decryptor.decrypt(Y[c], p);
+        encoder.decode(p, out);
+        double err = 0;
+        for (int j = 0; j < num_X; j++)
+            for (int k = 0; k < num_row; k++)
+            {
+                double e = 0;
+                for (int r = 0; r < num_col; r++)
+                    e += X[j][k][r] * W[r][c];
+                err = max(err, fabs(out[num_X * k + j] - e));
+            }
+        CHECK(err < 1e-4);
+        CHECK(context.get_context_data(Y[c].parms_id())->chain_index() ==
+              context.get_context_data(enc_X[0].parms_id())->chain_index() - 1);
+    }
+
+    // ---- ct_ct_matrix_mul_colpacking ------------------------------------------------------------------
+    {
+        const int cols = 3, rows = 4, num_batch = num_X;
+        vector<vector<double>> a(cols, vector<double>(slots)), b(cols, vector<double>(slots));
+        vector<Ciphertext> ea(cols), eb(cols);
+        Encryptor encryptor(context, pk);
+        for (int j = 0; j < cols; j++)
+        {
+            for (size_t s = 0; s < slots; s++)
+            {
+                a[j][s] = 0.5 * sin(0.01 * s + j);
+                b[j][s] = 0.5 * cos(0.02 * s - j);
+            }
+            Plaintext pa, pb;
+            encoder.encode(a[j], scale, pa);
+            encoder.encode(b[j], scale, pb);
+            encryptor.encrypt(pa, ea[j]);
+            encryptor.encrypt(pb, eb[j]);
+        }
+        vector<Ciphertext> out =
+            ct_ct_matrix_mul_colpacking(ea, eb, gal_keys, relin_keys, context, cols, rows, cols, rows, num_batch);
+        CHECK(out.size() == (size_t)rows);
+        for (int i = 0; i < rows; i++)
+        {
+            Plaintext p;
+            vector<double> dec;
+            decryptor.decrypt(out[i], p);
+            encoder.decode(p, dec);
+            double err = 0;
+            for (size_t s = 0; s < slots; s++)
+            {
+                double e = 0;
+                for (int j = 0; j < cols; j++)
+                    e += a[j][s] * b[j][(s + (size_t)i * num_batch) % slots];
+                err = max(err, fabs(dec[s] - e));
+            }
+            CHECK(err < 1e-4);
+        }
+    }
+
+    // ---- gelu_v2 (degree-24 polynomial, the GELU the 12-layer run uses: test_full_scheme.hpp:886) ----
+    {
+        Encryptor encryptor(context, pk);
+        vector<double> x(slots);
+        for (size_t s = 0; s < slots; s++)
+            x[s] = -3.0 + 6.0 * (double)s / (double)slots;
+        Plaintext px;
+        encoder.encode(x, scale, px);
+        Ciphertext cx;
+        encryptor.encrypt(px, cx);
+        Ciphertext g = gelu_v2(cx, context, relin_keys, sk);
+        Plaintext p;
+        vector<double> dec;
+        decryptor.decrypt(g, p);
+        encoder.decode(p, dec);
+        double err = 0;
+        for (size_t s = 0; s < slots; s++)
+        {
+            double ref = 0.5 * x[s] * (1.0 + erf(x[s] / sqrt(2.0)));
+            err = max(err, fabs(dec[s] - ref));
+        }
+        printf("gelu_v2 max |error| vs exact GELU on [-3,3]: %.3e\n", err);
+        CHECK(err < 5e-2);
+    }
+
+    if (!g_fail)
+    {
+        printf("ALL PASS\n");
+    }
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,354 @@
+// test_seal_shim.cpp -- exercises the seal:: surface (seal_shim/seal/seal.h) end to end on the GPU the
+// way the reference's own evaluator tests do: encode -> encrypt -> evaluate -> decrypt -> decode and
+// compare with the plain computation (native/tests/seal/evaluator.cpp:2971-4293), plus the exception
+// behaviour MOAI relies on.  Prints "ALL PASS" on success.
+#include <cstdio>
+#include <iostream>
+
+#include "seal/seal.h"
+
+using namespace seal;
+using namespace std;
+
+static int g_checks = 0, g_fail = 0;
+#define CHECK(cond)                                                          \
+    do                                                                       \
+    {                                                                        \
+        g_checks++;                                                          \
+        if (!(cond))                                                         \
+        {                                                                    \
+            g_fail++;                                                        \
+            printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+        }                                                                    \
+    } while (0)
+#define CHECK_THROWS(expr, extype)                                           \
+    do                                                                       \
+    {                                                                        \
+        g_checks++;                                                          \
+        bool caught = false;                                                 \
+        try                                                                  \
+        {                                                                    \
+            expr;                                                            \
+        }                                                                    \
+        catch (const extype &)                                               \
+        {                                                                    \
+            caught = true;                                                   \
+        }                                                                    \
+        catch (...)                                                          \
+        {}                                                                   \
+        if (!caught)                                                         \
+        {                                                                    \
+            g_fail++;                                                        \
+            printf("CHECK_THROWS FAILED %s:%d: %s\n", __FILE__, __LINE__, #expr); \
+        }                                                                    \
+    } while (0)
+
+static double max_err(const vector<double> &a, const vector<double> &b, size_t count)
+{
+    double m = 0;
+    for (size_t i = 0; i < count; i++)
+    {
+        m = max(m, fabs(a[i] - b[i]));
+    }
+    return m;
+}
+
+// BASELINE.json configs[0] / SURVEY.md 8(d) config 1
+static void config1()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t n = 8192;
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(CoeffModulus::Create(n, { 60, 40, 60 }));
+    SEALContext context(parms, true, sec_level_type::none);
+    CHECK(parms.coeff_modulus()[0].value() == 1152921504606748673ULL);
+    CHECK(parms.coeff_modulus()[1].value() == 1099511480321ULL);
+    CHECK(parms.coeff_modulus()[2].value() == 1152921504606830593ULL);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    CKKSEncoder encoder(context);
+    Encryptor encryptor(context, pk);
+    Decryptor decryptor(context, keygen.secret_key());
+    Evaluator evaluator(context, encoder);
+    double scale = pow(2.0, 40);
+    vector<double> v(encoder.slot_count());
+    for (size_t i = 0; i < v.size(); i++)
+    {
+        v[i] = i * 1e-3;
+    }
+    Plaintext pt, w;
+    encoder.encode(v, scale, pt);
+    Ciphertext ct;
+    encryptor.encrypt(pt, ct);
+    CHECK(context.get_context_data(ct.parms_id())->chain_index() == 1);
+    encoder.encode(0.5, ct.parms_id(), scale, w);
+    evaluator.multiply_plain_inplace(ct, w);
+    evaluator.rescale_to_next_inplace(ct);
+    CHECK(context.get_context_data(ct.parms_id())->chain_index() == 0);
+    Plaintext res;
+    decryptor.decrypt(ct, res);
+    vector<double> out;
+    encoder.decode(res, out);
+    CHECK(fabs(out[1000] - 0.5) < 1e-5);
+    vector<double> expect(v.size());
+    for (size_t i = 0; i < v.size(); i++)
+    {
+        expect[i] = v[i] * 0.5;
+    }
+    CHECK(max_err(out, expect, v.size()) < 1e-4);
+    CHECK_THROWS(evaluator.rescale_to_next_inplace(ct), invalid_argument); // end of chain
+}
+
+static void evaluator_ops()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t n = 4096;
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(CoeffModulus::Create(n, { 60, 40, 40, 40, 60 }));
+    parms.set_secret_key_hamming_weight(64);
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    RelinKeys rk;
+    GaloisKeys gk;
+    keygen.create_public_key(pk);
+    keygen.create_relin_keys(rk);
+    keygen.create_galois_keys(gk);
+    CKKSEncoder encoder(context);
+    Encryptor encryptor(context, pk);
+    Decryptor decryptor(context, keygen.secret_key());
+    Evaluator evaluator(context, encoder);
+    const size_t slots = encoder.slot_count();
+    const double scale = pow(2.0, 40);
+    vector<double> a(slots), b(slots), out;
+    for (size_t i = 0; i < slots; i++)
+    {
+        a[i] = sin(0.01 * i) + 0.5;
+        b[i] = cos(0.02 * i) - 0.25;
+    }
+    Plaintext pa, pb, pr;
+    encoder.encode(a, scale, pa);
+    encoder.encode(b, scale, pb);
+    Ciphertext ca, cb, c;
+    encryptor.encrypt(pa, ca);
+    encryptor.encrypt(pb, cb);
+    auto dec = [&](const Ciphertext &x) {
+        decryptor.decrypt(x, pr);
+        encoder.decode(pr, out);
+    };
+    vector<double> e(slots);
+
+    // encode/decode and encrypt/decrypt round trip
+    dec(ca);
+    CHECK(max_err(out, a, slots) < 1e-6);
+
+    // add / sub / negate
+    evaluator.add(ca, cb, c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] + b[i];
+    CHECK(max_err(out, e, slots) < 1e-6);
+    evaluator.sub(ca, cb, c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] - b[i];
+    CHECK(max_err(out, e, slots) < 1e-6);
+    evaluator.negate(ca, c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = -a[i];
+    CHECK(max_err(out, e, slots) < 1e-6);
+
+    // multiply -> size 3 decrypts; relinearize; rescale
+    evaluator.multiply(ca, cb, c);
+    CHECK(c.size() == 3);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] * b[i];
+    CHECK(max_err(out, e, slots) < 1e-5);
+    evaluator.relinearize_inplace(c, rk);
+    CHECK(c.size() == 2);
+    evaluator.rescale_to_next_inplace(c);
+    CHECK(context.get_context_data(c.parms_id())->chain_index() == 2);
+    CHECK(fabs(c.scale() / pow(2.0, 40) - 1.0) < 1e-4);
+    dec(c);
+    CHECK(max_err(out, e, slots) < 1e-5);
+
+    // sum of size-3 products then one relinearization (Ct_ct_matrix_mul.hpp:33-46)
+    {
+        Ciphertext acc, t;
+        evaluator.multiply(ca, cb, acc);
+        evaluator.multiply(cb, cb, t);
+        evaluator.add_inplace(acc, t);
+        evaluator.relinearize_inplace(acc, rk);
+        evaluator.rescale_to_next_inplace(acc);
+        dec(acc);
+        for (size_t i = 0; i < slots; i++) e[i] = a[i] * b[i] + b[i] * b[i];
+        CHECK(max_err(out, e, slots) < 1e-5);
+    }
+
+    // square
+    evaluator.square(ca, c);
+    evaluator.relinearize_inplace(c, rk);
+    evaluator.rescale_to_next_inplace(c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] * a[i];
+    CHECK(max_err(out, e, slots) < 1e-5);
+
+    // rotations: power of two (key present), 3 (NAF: 4 - 1), negative, conjugate
+    for (int steps : { 1, 3, -5, 256, 700 })
+    {
+        evaluator.rotate_vector(ca, steps, gk, c);
+        dec(c);
+        for (size_t i = 0; i < slots; i++) e[i] = a[(i + slots + steps) % slots];
+        CHECK(max_err(out, e, slots) < 1e-5);
+    }
+    evaluator.complex_conjugate(ca, gk, c);
+    dec(c);
+    CHECK(max_err(out, a, slots) < 1e-5); // real input
+    {
+        GaloisKeys only1;
+        keygen.create_galois_keys(vector<int>{ 1 }, only1);
+        Ciphertext t = ca;
+        CHECK_THROWS(evaluator.rotate_vector_inplace(t, 2, only1), invalid_argument); // Galois key not present
+        evaluator.rotate_vector_inplace(t, 1, only1);
+        dec(t);
+        for (size_t i = 0; i < slots; i++) e[i] = a[(i + 1) % slots];
+        CHECK(max_err(out, e, slots) < 1e-5);
+    }
+
+    // plain ops: vector and scalar plaintexts
+    evaluator.add_plain(ca, pb, c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] + b[i];
+    CHECK(max_err(out, e, slots) < 1e-6);
+    evaluator.sub_plain(ca, pb, c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] - b[i];
+    CHECK(max_err(out, e, slots) < 1e-6);
+    evaluator.multiply_plain(ca, pb, c);
+    evaluator.rescale_to_next_inplace(c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] * b[i];
+    CHECK(max_err(out, e, slots) < 1e-5);
+    {
+        Plaintext s;
+        encoder.encode(-1.75, ca.parms_id(), ca.scale(), s);
+        evaluator.add_plain(ca, s, c);
+        dec(c);
+        for (size_t i = 0; i < slots; i++) e[i] = a[i] - 1.75;
+        CHECK(max_err(out, e, slots) < 1e-6);
+        evaluator.sub_plain(ca, s, c);
+        dec(c);
+        for (size_t i = 0; i < slots; i++) e[i] = a[i] + 1.75;
+        CHECK(max_err(out, e, slots) < 1e-6);
+        evaluator.multiply_plain(ca, s, c);
+        evaluator.rescale_to_next_inplace(c);
+        dec(c);
+        for (size_t i = 0; i < slots; i++) e[i] = a[i] * -1.75;
+        CHECK(max_err(out, e, slots) < 1e-5);
+        vector<double> sd;
+        encoder.decode(s, sd);
+        CHECK(fabs(sd[0] + 1.75) < 1e-9 && fabs(sd[slots - 1] + 1.75) < 1e-9);
+    }
+
+    // level management
+    {
+        Ciphertext t = ca;
+        auto last_id = context.last_parms_id();
+        evaluator.mod_switch_to_inplace(t, last_id);
+        CHECK(t.coeff_modulus_size() == 1 && t.parms_id() == last_id);
+        dec(t);
+        CHECK(max_err(out, a, slots) < 1e-6);
+        CHECK_THROWS(evaluator.mod_switch_to_next_inplace(t), invalid_argument);
+        CHECK_THROWS(evaluator.mod_switch_to_inplace(t, context.first_parms_id()), invalid_argument);
+        Plaintext p2 = pa;
+        evaluator.mod_switch_to_inplace(p2, last_id);
+        CHECK_THROWS(evaluator.add_plain_inplace(c = ca, p2), invalid_argument); // parameter mismatch
+        evaluator.add_plain_inplace(t, p2);
+        dec(t);
+        for (size_t i = 0; i < slots; i++) e[i] = 2 * a[i];
+        CHECK(max_err(out, e, slots) < 1e-6);
+    }
+
+    // error behaviour MOAI depends on: scale mismatch is an exception (Ct_pt_matrix_mul.hpp:41 resets scale)
+    {
+        Ciphertext t;
+        evaluator.multiply_plain(ca, pb, t);
+        evaluator.rescale_to_next_inplace(t);
+        Ciphertext u = ca;
+        evaluator.mod_switch_to_next_inplace(u);
+        CHECK_THROWS(evaluator.add_inplace(t, u), invalid_argument); // scale mismatch
+        t.scale() = u.scale();
+        evaluator.add_inplace(t, u);
+        CHECK_THROWS(evaluator.add_inplace(t, ca), invalid_argument); // parms mismatch
+    }
+
+    // fork additions
+    evaluator.add_const(ca, 2.5, c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] + 2.5;
+    CHECK(max_err(out, e, slots) < 1e-6);
+    evaluator.multiply_const(ca, -0.5, c);
+    evaluator.rescale_to_next_inplace(c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] * -0.5;
+    CHECK(max_err(out, e, slots) < 1e-5);
+    evaluator.multiply_vector_reduced_error(ca, b, c);
+    evaluator.rescale_to_next_inplace(c);
+    dec(c);
+    for (size_t i = 0; i < slots; i++) e[i] = a[i] * b[i];
+    CHECK(max_err(out, e, slots) < 1e-5);
+    {
+        // operands at different levels
+        Ciphertext lo;
+        evaluator.multiply_const(cb, 1.0, lo);
+        evaluator.rescale_to_next_inplace(lo); // one level below ca, scale ~2^40
+        Ciphertext r;
+        evaluator.add_reduced_error(ca, lo, r);
+        dec(r);
+        for (size_t i = 0; i < slots; i++) e[i] = a[i] + b[i];
+        CHECK(max_err(out, e, slots) < 1e-4);
+        evaluator.sub_reduced_error(lo, ca, r);
+        dec(r);
+        for (size_t i = 0; i < slots; i++) e[i] = b[i] - a[i];
+        CHECK(max_err(out, e, slots) < 1e-4);
+        evaluator.multiply_reduced_error(ca, lo, rk, r);
+        evaluator.rescale_to_next_inplace(r);
+        dec(r);
+        for (size_t i = 0; i < slots; i++) e[i] = a[i] * b[i];
+        CHECK(max_err(out, e, slots) < 1e-4);
+        evaluator.double_inplace(r);
+        dec(r);
+        for (size_t i = 0; i < slots; i++) e[i] = 2 * a[i] * b[i];
+        CHECK(max_err(out, e, slots) < 2e-4);
+    }
+
+    // NTT form round trip on a ciphertext (Bootstrapper::modraise_inplace uses these)
+    {
+        Ciphertext t = ca;
+        auto before = t.download();
+        evaluator.transform_from_ntt_inplace(t);
+        CHECK(!t.is_ntt_form());
+        evaluator.transform_to_ntt_inplace(t);
+        CHECK(t.download() == before);
+        CHECK_THROWS(evaluator.transform_to_ntt_inplace(t), invalid_argument);
+    }
+}
+
+int main()
+{
+    try
+    {
+        config1();
+        evaluator_ops();
+    }
+    catch (const std::exception &e)
+    {
+        printf("EXCEPTION: %s\n", e.what());
+        return 2;
+    }
+    printf("%d checks, %d failed\n", g_checks, g_fail);
+    if (!g_fail)
+    {
+        printf("ALL PASS\n");
+    }
+    return g_fail ? 1 : 0;
+}

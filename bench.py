@@ -89,21 +89,15 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    m.shard.barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    m.shard.barrier(dist)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = m.shard.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
     # round trip must be the identity (bit exact)
     assert torch.equal(data[0, 0, :, :], sample_before), "INTT(NTT(x)) != x"

@@ -4,5 +4,5 @@ Everything here is a thin host binding over the C ABI of `libmoai_hip.so` (inclu
 holds the hand-written gfx950 kernels.  There is no CPU fallback: importing `hip` raises if the
 shared library has not been built (python __graft_entry__.py build, or make -C csrc).
 """
-from . import hip  # noqa: F401
+from . import hip, shard  # noqa: F401
 from .hip import Context, DeviceBuffer, MoaiError, lib_path  # noqa: F401

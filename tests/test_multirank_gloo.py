@@ -1,0 +1,64 @@
+"""The N > 1 path of bench.py on CPU: world_size 2 over gloo.  The data path has no collective; what is
+distributed is the sharding of the ciphertext batch and the barrier / max-over-ranks timing."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = g.load_package()
+    start, count = m.shard.shard_range(257, rank, world)
+    m.shard.barrier(dist)
+    # rank 1 is "slower": the job takes as long as the slowest rank
+    seconds = 2.0 if rank == 1 else 1.0
+    t = m.shard.max_over_ranks(seconds, dist)
+    rate = m.shard.whole_job_rate(float(count), seconds, dist)
+    m.shard.barrier(dist)
+    q.put((rank, start, count, t, rate))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, c0, t0, rate0), (r1, s1, c1, t1, rate1) = res
+    assert (s0, c0) == (0, 129) and (s1, c1) == (129, 128)  # disjoint, covers all 257 ciphertexts
+    assert t0 == t1 == 2.0  # max over ranks
+    assert rate0 == rate1 == pytest.approx(257 / 2.0)  # all units / slowest rank
+
+
+def test_shard_range_properties():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+
+    m = g.load_package()
+    for total in (0, 1, 7, 256, 257, 768):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                s, c = m.shard.shard_range(total, r, world)
+                cover += list(range(s, s + c))
+            assert cover == list(range(total))
+    with pytest.raises(ValueError):
+        m.shard.shard_range(8, 2, 2)

@@ -308,6 +308,10 @@ static int check_level(const moai_ctx *c, size_t L, size_t polys)
     return MOAI_OK;
 }
 
+template <int LOGN>
+static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
+                          size_t batch, const KsGroup &grp, size_t G, hipStream_t s);
+
 // number of output moduli whose digits are in flight at once: bounded by the scratch budget
 // (MOAI_KS_TMP_MB, default 2048 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
 // one launch while large batches stay within a few GiB of workspace
@@ -350,9 +354,26 @@ static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
            align256(batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
 }
 
-template <int LOGN>
-static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, hipStream_t s)
+// which arithmetic discipline the primes of this context allow (keyswitch_kernels.cuh)
+static int ks_mode(const moai_ctx *c, size_t L)
+{
+    uint64_t qmax = 0;
+    for (uint64_t q : c->primes)
+    {
+        qmax = q > qmax ? q : qmax;
+    }
+    if (!noguard_ok(qmax))
+    {
+        return 0;
+    }
+    // 36 q * q * L < 2^128: the lazy digit may enter the 128-bit accumulator unreduced
+    unsigned __int128 lim = (unsigned __int128)qmax * qmax;
+    return lim < ((~(unsigned __int128)0) / (36 * (unsigned __int128)(L ? L : 1))) ? 1 : 0;
+}
+
+template <int LOGN, int MODE>
+static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
+                               size_t batch, const KsGroup &grp, size_t G, hipStream_t s)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     KsP1Args p1;
@@ -364,7 +385,7 @@ static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const u
     p1.L = (uint32_t)L;
     p1.G = (uint32_t)G;
     p1.total_work = (uint32_t)(batch * G * L * TPR);
-    hipLaunchKernelGGL(ks_fwd_strided<LOGN>, dim3(p1.total_work), dim3(256), 0, s, p1);
+    hipLaunchKernelGGL((ks_fwd_strided<LOGN, MODE>), dim3(p1.total_work), dim3(256), 0, s, p1);
     MOAI_LAUNCH_CHECK();
     KsP2Args p2;
     p2.tmp = tmp;
@@ -377,9 +398,20 @@ static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const u
     p2.G = (uint32_t)G;
     p2.k = (uint32_t)c->k;
     p2.total_work = (uint32_t)(batch * G * TPR);
-    hipLaunchKernelGGL(ks_contig_mac<LOGN>, dim3(p2.total_work), dim3(256), 0, s, p2);
+    hipLaunchKernelGGL((ks_contig_mac<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
+}
+
+template <int LOGN>
+static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
+                          size_t batch, const KsGroup &grp, size_t G, hipStream_t s)
+{
+    if (ks_mode(c, L))
+    {
+        return ks_fused_group_mode<LOGN, 1>(c, t, tmp, key, acc, L, batch, grp, G, s);
+    }
+    return ks_fused_group_mode<LOGN, 0>(c, t, tmp, key, acc, L, batch, grp, G, s);
 }
 
 // target row block of ciphertext b starts at target + (b * target_stride_rows + target_off_rows) * N.

@@ -33,7 +33,10 @@ struct KsP1Args
 };
 
 // work id -> (tile fastest, then group member, digit, ciphertext): neighbours read the same digit tile
-template <int LOGN>
+// MODE 0: reference discipline (guard per butterfly, digits normalised with two conditional subtracts)
+// MODE 1: every prime below 2^64/36 and 36 q^2 L < 2^128 (MOAI's chain): no guards, and the
+//         unreduced digit (< 33q) goes straight into the 128-bit MAC
+template <int LOGN, int MODE>
 __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
     op.cr1 = pc->cr1;
     const uint64_t *in = a.t + (((size_t)b * a.L + J) << LOGN);
     uint64_t *out = a.tmp + ((((size_t)b * a.G + g) * a.L + J) << LOGN);
-    fwd_strided_tile<LOGN, LoadBarrett>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds, threadIdx.x,
-                                        op);
+    fwd_strided_tile<LOGN, LoadBarrett, (MODE != 0)>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds,
+                                                     threadIdx.x, op);
 }
 
 struct KsP2Args
@@ -78,7 +81,7 @@ __device__ __forceinline__ void mac128r(uint64_t &lo, uint64_t &hi, uint64_t a, 
     hi += ph + (lo < pl ? 1 : 0);
 }
 
-template <int LOGN>
+template <int LOGN, int MODE>
 __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
 {
     constexpr int R1 = LOGN - 8;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
                 if (!(j & half))
                 {
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
-                    ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
                 {
                     uint32_t t_ = (tl << 4) | (uint32_t)j;
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
-                    ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
@@ -165,8 +168,16 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
         for (int c = 0; c < 8; ++c)
         {
             ulonglong2 v;
-            v.x = csub(csub(x[2 * c], q2), q);
-            v.y = csub(csub(x[2 * c + 1], q2), q);
+            if (MODE == 0)
+            {
+                v.x = csub(csub(x[2 * c], q2), q);
+                v.y = csub(csub(x[2 * c + 1], q2), q);
+            }
+            else
+            {
+                v.x = x[2 * c];
+                v.y = x[2 * c + 1];
+            }
             lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
         }
         __syncthreads();

@@ -12,11 +12,13 @@ __device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b)
 }
 
 // Shoup lazy product: y * w mod q in [0, 2q) for ANY 64-bit y, given wq = floor(w * 2^64 / q)
-// (multiply_uint_mod_lazy, uintarithsmallmod.h:313-326).
+// (multiply_uint_mod_lazy, uintarithsmallmod.h:313-326).  Written as y*w + t*(-q) so that the two
+// low products accumulate in one v_mad_u64_u32 chain instead of ending in a 64-bit subtract
+// (v_sub_co / v_subb_co plus a VCC wait state on gfx950).
 __device__ __forceinline__ uint64_t mul_shoup_lazy(uint64_t y, uint64_t w, uint64_t wq, uint64_t q)
 {
     uint64_t t = mulhi64(y, wq);
-    return y * w - t * q;
+    return y * w + t * (0 - q);
 }
 
 __device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m)
@@ -70,6 +72,35 @@ __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, ui
     uint64_t v = mul_shoup_lazy(y, w, wq, q);
     x = u + v;
     y = u + q2 - v;
+}
+
+// Cooley-Tukey butterfly without the guard: values grow by 2q per stage, so 16 stages starting below
+// 4q stay below 36q.  Used when 36q < 2^64 (every prime of MOAI's chain, <= 58 bits); the pass that
+// finishes the transform reduces with one Barrett step.  Same residues as ct_bfly.
+__device__ __forceinline__ void ct_bfly_noguard(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
+{
+#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
+    x += y + w;
+    y ^= wq + q + q2;
+    return;
+#endif
+    uint64_t v = mul_shoup_lazy(y, w, wq, q);
+    uint64_t u = x;
+    x = u + v;
+    y = u + q2 - v;
+}
+
+template <bool NOGUARD>
+__device__ __forceinline__ void ct_bfly_t(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
+{
+    if (NOGUARD)
+    {
+        ct_bfly_noguard(x, y, w, wq, q, q2);
+    }
+    else
+    {
+        ct_bfly(x, y, w, wq, q, q2);
+    }
 }
 
 // Gentleman-Sande butterfly, lazy: x, y in [0, 2q) -> [0, 2q)   (dwthandler.h:226-250)

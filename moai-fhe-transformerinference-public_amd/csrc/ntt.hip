@@ -18,13 +18,21 @@ static bool naive_requested()
 }
 
 template <int LOGN>
-static void launch_fwd(const NttArgs &base, hipStream_t s)
+static void launch_fwd(const NttArgs &base, bool noguard, hipStream_t s)
 {
     NttArgs a = base;
     constexpr uint32_t tpr_strided = 1u << (LOGN - 12);
     a.total_work = a.n_poly * a.L * tpr_strided;
-    hipLaunchKernelGGL(ntt_fwd_strided<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(ntt_fwd_contig<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
+    if (noguard)
+    {
+        hipLaunchKernelGGL((ntt_fwd_strided<LOGN, true>), dim3(a.total_work), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((ntt_fwd_contig<LOGN, true>), dim3(a.total_work), dim3(256), 0, s, a);
+    }
+    else
+    {
+        hipLaunchKernelGGL((ntt_fwd_strided<LOGN, false>), dim3(a.total_work), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((ntt_fwd_contig<LOGN, false>), dim3(a.total_work), dim3(256), 0, s, a);
+    }
 }
 
 template <int LOGN>
@@ -41,6 +49,14 @@ static long env_long(const char *name, long dflt)
 {
     const char *e = getenv(name);
     return e ? atol(e) : dflt;
+}
+
+} // namespace moai
+namespace moai {
+// 36 q < 2^64: forward butterflies may skip the per-stage guard (modarith.cuh ct_bfly_noguard)
+bool noguard_ok(uint64_t q)
+{
+    return q < (~0ull) / 36;
 }
 
 // single-launch transform (ntt_coop); its queue state lives in a per-stream arena
@@ -215,6 +231,12 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
             }
         }
     }
+    // every prime of this launch small enough for 16 unguarded stages (input < 4q, +2q per stage)?
+    bool noguard = !inverse;
+    for (size_t r = 0; r < L && noguard; ++r)
+    {
+        noguard = noguard_ok(c->primes[rows.idx[r]]);
+    }
 #define MOAI_NTT_CASE(LG)               \
     case LG:                            \
         if (inverse)                    \
@@ -223,7 +245,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
         }                               \
         else                            \
         {                               \
-            launch_fwd<LG>(a, s);       \
+            launch_fwd<LG>(a, noguard, s); \
         }                               \
         break;
     for (size_t p0 = 0; p0 < n_poly; p0 += chunk)

@@ -89,7 +89,7 @@ struct LoadBarrett
 };
 
 // one tile of the strided pass: reads row `inp`, writes row `outp` (may be the same row)
-template <int LOGN, class LoadOp = LoadIdentity>
+template <int LOGN, class LoadOp = LoadIdentity, bool NOGUARD = false>
 __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
                                                  const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
                                                  const uint32_t tid, LoadOp op = LoadOp())
@@ -119,7 +119,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
             if (!(j & half))
             {
                 Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -150,7 +150,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
                 {
                     uint32_t t_ = (th << 4) | (uint32_t)j;
                     Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
-                    ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
@@ -172,7 +172,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
     }
 }
 
-template <int LOGN>
+template <int LOGN, bool NOGUARD = false>
 __global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -182,16 +182,19 @@ __global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
     const uint32_t prow = w / TPR;
     const uint32_t prime = a.rows.idx[prow % a.L];
     uint64_t *rowp = a.data + ((size_t)prow << LOGN);
-    fwd_strided_tile<LOGN>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), a.pc[prime].q, a.pc[prime].q2, lds,
-                           threadIdx.x);
+    fwd_strided_tile<LOGN, LoadIdentity, NOGUARD>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), a.pc[prime].q,
+                                                  a.pc[prime].q2, lds, threadIdx.x);
 }
 
 // =====================================================================================================
 // forward, contiguous pass: stages LOGN-8 .. LOGN-1 on 16 consecutive 256-blocks; writes canonical
 // =====================================================================================================
-template <int LOGN>
+// NOGUARD: input below 20q (strided pass without guards), stages without guards, one Barrett step at
+// the end (cr1 = high word of floor(2^128/q)); otherwise the reference's [0,4q) discipline
+template <int LOGN, bool NOGUARD = false>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
-                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid)
+                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
+                                                uint64_t cr1 = 0)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
@@ -216,7 +219,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             if (!(j & half))
             {
                 Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -245,7 +248,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             {
                 uint32_t t_ = (tl << 4) | (uint32_t)j;
                 Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
-                ct_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -254,8 +257,16 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     for (int c = 0; c < 8; ++c)
     {
         ulonglong2 v;
-        v.x = csub(csub(x[2 * c], q2), q);
-        v.y = csub(csub(x[2 * c + 1], q2), q);
+        if (NOGUARD)
+        {
+            v.x = barrett64(x[2 * c], q, cr1);
+            v.y = barrett64(x[2 * c + 1], q, cr1);
+        }
+        else
+        {
+            v.x = csub(csub(x[2 * c], q2), q);
+            v.y = csub(csub(x[2 * c + 1], q2), q);
+        }
         lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
     }
     __syncthreads();
@@ -269,7 +280,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     }
 }
 
-template <int LOGN>
+template <int LOGN, bool NOGUARD = false>
 __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -280,8 +291,8 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
     const uint32_t tile = rest % TPR;
     const uint32_t r = rest / TPR;
     const uint32_t prime = a.rows.idx[r];
-    fwd_contig_tile<LOGN>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
-                          a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x);
+    fwd_contig_tile<LOGN, NOGUARD>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
+                                   a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x, a.pc[prime].cr1);
 }
 
 // =====================================================================================================

@@ -226,6 +226,40 @@ def test_switch_key_relin_galois(moai, env12, L):
             assert (got[b] == octx.apply_galois(ct[b], L, elt, key).reshape(2, L, n)).all()
 
 
+@pytest.mark.parametrize("bits", [[60, 50, 60, 61], [46, 58, 51, 58]])
+def test_switch_key_guarded_and_lazy_arithmetic(moai, bits):
+    """60/61-bit primes take the guarded butterflies and normalised MAC; <= 58-bit chains (MOAI) the
+    unguarded ones with the lazy 128-bit MAC.  Both must reproduce the oracle bit for bit."""
+    logn = 13
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k = len(primes)
+    rng = np.random.default_rng(sum(bits))
+    key = O.uniform_rns(rng, primes, (k - 1, 2), n)
+    # worst-case magnitudes: every residue q-1
+    for J in range(k - 1):
+        for K in range(2):
+            for i in range(k):
+                key[J, K, i, :64] = primes[i] - 1
+    dkey = up(moai, key)
+    for L in (3, 2):
+        ct = O.uniform_rns(rng, primes[:L], (2, 2), n)
+        tgt = O.uniform_rns(rng, primes[:L], (2,), n)
+        for i in range(L):
+            tgt[0, i, :64] = primes[i] - 1
+        dct, dt = up(moai, ct), up(moai, tgt)
+        ctx.switch_key(dct, dt, dkey, L, 2)
+        got = dct.to_numpy(ct.shape)
+        for b in range(2):
+            assert (got[b] == octx.switch_key(ct[b], tgt[b], key, L).reshape(2, L, n)).all(), (bits, L, b)
+    # the plain NTT under both disciplines, lazy [0,4q) input included in the unguarded bound
+    x = O.uniform_rns(rng, primes, (2,), n)
+    d = up(moai, x)
+    ctx.ntt_forward(d, 2, k)
+    assert (d.to_numpy(x.shape) == octx.ntt(x, k)).all()
+
+
 def test_keyswitch_decrypts(moai):
     """semantic end-to-end: encrypt -> rotate on the GPU -> decrypt gives the rotated message."""
     from ckks_toy import ToyClient, galois_coeffs

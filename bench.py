@@ -232,9 +232,10 @@ def cpu_baseline(primes, seconds, sample_before, data, ctx, stream):
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
     import oracle as O  # checker + baseline only
 
+    # torch has already initialised the OpenMP runtime, so the environment variable would come too late
+    O.lib().mo_set_threads(host_cores())
     threads = O.lib().mo_max_threads()
     octx = O.Context(LOGN, primes)
     # parity of one polynomial's 44 rows: GPU forward vs oracle forward

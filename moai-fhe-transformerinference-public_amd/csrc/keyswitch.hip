@@ -397,6 +397,7 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.L = (uint32_t)L;
     p2.G = (uint32_t)G;
     p2.k = (uint32_t)c->k;
+    p2.B = (uint32_t)batch;
     p2.total_work = (uint32_t)(batch * G * TPR);
     hipLaunchKernelGGL((ks_contig_mac<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
     MOAI_LAUNCH_CHECK();

@@ -70,6 +70,7 @@ struct KsP2Args
     uint32_t L;
     uint32_t G;
     uint32_t k;
+    uint32_t B;          // ciphertexts in the batch
     uint32_t total_work;
 };
 
@@ -89,11 +90,13 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
     __shared__ ulonglong2 lds2[2048];
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
 
+    // ciphertext index fastest: the workgroups that run side by side on one XCD walk the same key tiles
+    // (modulus I, tile, J = 0..L-1), so each key line is fetched from HBM once per XCD, not once per ciphertext
     uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t bq = w % a.B;
+    w /= a.B;
     const uint32_t tile = w % TPR;
-    w /= TPR;
-    const uint32_t g = w % a.G;
-    const uint32_t bq = w / a.G;
+    const uint32_t g = w / TPR;
     const uint32_t prime = a.grp.prime[g];
     const uint32_t slot = a.grp.slot[g];
     const PrimeConst *pc = a.pc + prime;

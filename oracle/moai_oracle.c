@@ -815,6 +815,18 @@ void mo_context_destroy(mo_context *c)
     free(c);
 }
 
+void mo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0)
+    {
+        omp_set_num_threads(n);
+    }
+#else
+    (void)n;
+#endif
+}
+
 int mo_max_threads(void)
 {
 #ifdef _OPENMP

@@ -162,6 +162,7 @@ void mo_modraise(const mo_context *c, const uint64_t *in, size_t Lout, uint64_t 
 
 /* number of OpenMP threads the batch helpers below will use */
 int mo_max_threads(void);
+void mo_set_threads(int n);
 /* batch helpers for the CPU baseline: loop the op over `batch` independent inputs with
  * `#pragma omp parallel for` over the ciphertext index, as MOAI does
  * (include/source/matrix_mul/Ct_pt_matrix_mul.hpp:19). */

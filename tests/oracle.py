@@ -116,6 +116,7 @@ def _declare(L):
         "mo_apply_galois_inplace": (None, [vp, vp, sz, C.c_uint32, vp]),
         "mo_modraise": (None, [vp, vp, sz, vp]),
         "mo_max_threads": (C.c_int, []),
+        "mo_set_threads": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -43,3 +43,32 @@ for L, B in [(35, 1), (35, 8), (35, 64), (21, 64), (15, 64), (3, 64), (35, 256)]
     ms = e1.elapsed_ms_since(e0) / reps
     print("L=%2d batch=%3d: %9.3f ms per call, %8.3f ms per ciphertext" % (L, B, ms, ms / B), flush=True)
     del ct
+
+
+# CPU baseline for the same operation: the oracle's restatement of SEAL's switch_key_inplace
+# (SEAL/evaluator.cpp:2724-3020) at MOAI parameters, OpenMP over ciphertexts like MOAI's loops
+if "--cpu" in sys.argv:
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle as O
+    O.lib().mo_set_threads(bench.host_cores())
+    octx = O.Context(16, primes)
+    threads = O.lib().mo_max_threads()
+    rng = np.random.default_rng(0)
+    hkey = key.cpu().numpy().view(np.uint64)
+    for L in (35, 15):
+        B = threads
+        cts = O.uniform_rns(rng, primes[:L], (B, 2), N)
+        tg = O.uniform_rns(rng, primes[:L], (B,), N)
+        t0 = time.perf_counter()
+        out = octx.batch_switch_key(cts, tg, hkey, L, B)
+        el = time.perf_counter() - t0
+        print("CPU oracle switch_key L=%2d: %d ciphertexts on %d threads in %.2f s -> %.1f ms per ciphertext (%.1f ms single-thread-equivalent)"
+              % (L, B, threads, el, el / B * 1e3, el * 1e3), flush=True)
+        # parity of ciphertext 0 against the GPU
+        dct = torch.from_numpy(cts[0:1].view(np.int64).copy()).to(dev)
+        dtg = torch.from_numpy(tg[0:1].view(np.int64).copy()).to(dev)
+        ctx.switch_key(dct.data_ptr(), dtg.data_ptr(), key.data_ptr(), L, 1, stream=st)
+        torch.cuda.synchronize()
+        assert (dct.cpu().numpy().view(np.uint64) == out[0:1]).all(), "GPU key switch differs from the oracle"
+        print("   GPU result of ciphertext 0 is bit-identical to the oracle")

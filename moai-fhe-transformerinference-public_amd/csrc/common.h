@@ -68,6 +68,10 @@ struct moai_ctx
     std::vector<moai::PrimeConst> pc_host;
     moai::Tw *fwd_tw = nullptr;        // [k][N]: index m+i = psi^bitrev(m+i)        (ntt.cpp:269-278)
     moai::Tw *inv_tw = nullptr;        // [k][N]: index m+i = psi^-bitrev(m+i) (same indexing as fwd)
+    // the twiddles of the last four stages of the contiguous pass, re-ordered so that the 256 threads of a
+    // workgroup read consecutive entries: [k][N/4096 tiles][15 slots][256 threads] (N >= 4096 only)
+    moai::Tw *fwd_twb = nullptr;
+    moai::Tw *inv_twb = nullptr;
     moai::PrimeConst *pc = nullptr;    // [k]
     // inv_q_last_mod_q[l][i] = q_l^-1 mod q_i as Shoup operands, l in [1,k), i < l  (rns.cpp:769-775)
     moai::Tw *inv_qlast = nullptr;     // [k][k]

@@ -292,6 +292,36 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         moai_ctx_destroy(c);
         return set_error(MOAI_EINVAL, "invalid modulus: no primitive 2N-th root");
     }
+    // per-thread ordering of the contiguous pass's last four stages (ntt_kernels.cuh fwd_contig_tile)
+    std::vector<Tw> fwdb, invb;
+    const size_t nb = logn >= 12 ? (n >> 12) * 15 * 256 : 0;
+    if (nb)
+    {
+        const int r1 = logn - 8;
+        fwdb.resize(k * nb);
+        invb.resize(k * nb);
+        for (size_t p = 0; p < k; p++)
+        {
+            for (size_t tile = 0; tile < (n >> 12); tile++)
+            {
+                for (int u = 4; u < 8; u++)
+                {
+                    for (uint32_t i2 = 0; i2 < (1u << (u - 4)); i2++)
+                    {
+                        const size_t slot = (1u << (u - 4)) - 1 + i2;
+                        for (uint32_t tid = 0; tid < 256; tid++)
+                        {
+                            const uint32_t b = tid >> 4, tl = tid & 15u;
+                            const size_t src = ((size_t)1 << (r1 + u)) + ((tile * 16 + b) << u) + ((tl << (u - 4)) | i2);
+                            const size_t dst = p * nb + ((tile * 15 + slot) << 8) + tid;
+                            fwdb[dst] = fwd[p * n + src];
+                            invb[dst] = inv[p * n + src];
+                        }
+                    }
+                }
+            }
+        }
+    }
     // inv_qlast[l*k + i] = q_l^-1 mod q_i  (for all l != i; the rescale uses l = L-1 > i, the
     // key-switch mod-down uses l = k-1)
     c->inv_qlast_host.assign(k * k, Tw{ 0, 0 });
@@ -311,6 +341,10 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         (e = hipMalloc(&c->inv_tw, sizeof(Tw) * k * n)) != hipSuccess ||
         (e = hipMalloc(&c->pc, sizeof(PrimeConst) * k)) != hipSuccess ||
         (e = hipMalloc(&c->inv_qlast, sizeof(Tw) * k * k)) != hipSuccess ||
+        (nb && (e = hipMalloc(&c->fwd_twb, sizeof(Tw) * k * nb)) != hipSuccess) ||
+        (nb && (e = hipMalloc(&c->inv_twb, sizeof(Tw) * k * nb)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->fwd_twb, fwdb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->inv_twb, invb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
         (e = hipMemcpy(c->fwd_tw, fwd.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(c->inv_tw, inv.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(c->pc, c->pc_host.data(), sizeof(PrimeConst) * k, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -335,6 +369,8 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
     (void)hipFree(c->inv_tw);
     (void)hipFree(c->pc);
     (void)hipFree(c->inv_qlast);
+    (void)hipFree(c->fwd_twb);
+    (void)hipFree(c->inv_twb);
     for (auto &kv : c->ws)
     {
         (void)hipFree(kv.second.ptr);

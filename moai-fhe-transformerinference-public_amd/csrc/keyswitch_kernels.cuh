@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
             {
                 if (!(j & half))
                 {
+                    // the plain table here: the same 15 entries per thread are re-read for every digit J, and a
+                    // thread's 8 last-stage entries share one 128-byte line (measured faster than the
+                    // per-thread-ordered copy the NTT kernels use)
                     uint32_t t_ = (tl << 4) | (uint32_t)j;
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
                     ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);

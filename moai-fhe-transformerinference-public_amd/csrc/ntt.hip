@@ -138,6 +138,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     NttArgs a;
     a.data = data;
     a.tw = inverse ? c->inv_tw : c->fwd_tw;
+    a.twb = inverse ? c->inv_twb : c->fwd_twb;
     a.pc = c->pc;
     a.rows = rows;
     a.L = (uint32_t)L;

@@ -59,6 +59,7 @@ struct NttArgs
 {
     uint64_t *data;            // [n_poly][L][N]
     const Tw *tw;              // fwd or inv table, [k][N]
+    const Tw *twb;             // same direction, per-thread order for the contiguous pass's last 4 stages
     const PrimeConst *pc;      // [k]
     RowMap rows;               // row r -> prime
     uint32_t L;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
 template <int LOGN, bool NOGUARD = false>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
-                                                uint64_t cr1 = 0)
+                                                const Tw *__restrict__ twb, uint64_t cr1 = 0)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
@@ -202,6 +203,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     const uint32_t b = tid >> 4;
     const uint32_t tl = tid & 15u;
     const uint32_t blk = (tile << 4) + b;
+    const Tw *__restrict__ twbt = twb + (size_t)tile * (15 * 256);
 
     uint64_t x[16];
 #pragma unroll
@@ -246,8 +248,8 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
         {
             if (!(j & half))
             {
-                uint32_t t_ = (tl << 4) | (uint32_t)j;
-                Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
+                // slot = 2^(u-4) - 1 + (j >> (8-u)); consecutive threads read consecutive entries
+                Tw t = twbt[(((1u << (u - 4)) - 1u + (uint32_t)(j >> (8 - u))) << 8) + tid];
                 ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
@@ -292,7 +294,8 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
     const uint32_t r = rest / TPR;
     const uint32_t prime = a.rows.idx[r];
     fwd_contig_tile<LOGN, NOGUARD>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
-                                   a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x, a.pc[prime].cr1);
+                                   a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x,
+                                   a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), a.pc[prime].cr1);
 }
 
 // =====================================================================================================
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 // =====================================================================================================
 template <int LOGN>
 __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
-                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid)
+                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
+                                                const Tw *__restrict__ twb)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
@@ -308,6 +312,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
     const uint32_t b = tid >> 4;
     const uint32_t tl = tid & 15u;
     const uint32_t blk = (tile << 4) + b;
+    const Tw *__restrict__ twbt = twb + (size_t)tile * (15 * 256);
 
     const ulonglong2 *__restrict__ in2 = reinterpret_cast<const ulonglong2 *>(base);
 #pragma unroll
@@ -336,8 +341,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
         {
             if (!(j & half))
             {
-                uint32_t t_ = (tl << 4) | (uint32_t)j;
-                Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
+                Tw t = twbt[(((1u << (u - 4)) - 1u + (uint32_t)(j >> (8 - u))) << 8) + tid];
                 gs_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
@@ -390,7 +394,8 @@ __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
     const uint32_t r = rest / TPR;
     const uint32_t prime = a.rows.idx[r];
     inv_contig_tile<LOGN>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
-                          a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x);
+                          a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x,
+                          a.twb + (size_t)prime * ((size_t)TPR * 15 * 256));
 }
 
 // =====================================================================================================
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(256, WPS) void ntt_coop(NttArgs a, CoopArgs c)
         {
             if (INV)
             {
-                inv_contig_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds2, tid);
+                inv_contig_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds2, tid, a.twb + (size_t)prime * ((size_t)TPR * 15 * 256));
             }
             else
             {
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(256, WPS) void ntt_coop(NttArgs a, CoopArgs c)
             }
             else
             {
-                fwd_contig_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds2, tid);
+                fwd_contig_tile<LOGN>(rowp, tile, tw, pc->q, pc->q2, lds2, tid, a.twb + (size_t)prime * ((size_t)TPR * 15 * 256));
             }
         }
     }

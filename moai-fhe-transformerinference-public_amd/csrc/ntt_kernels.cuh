@@ -653,7 +653,10 @@ __global__ __launch_bounds__(256, WPS) void ntt_coop(NttArgs a, CoopArgs c)
             }
             continue;
         }
-        const uint32_t prow = v - 2;
+        // tickets run prime-major (polynomial index fastest) so that all XCDs work under the same prime
+        // at the same time and its twiddle tables stay resident in every L2
+        const uint32_t ticket = v - 2;
+        const uint32_t prow = (ticket % a.n_poly) * a.L + ticket / a.n_poly;
         const uint32_t prime = a.rows.idx[prow % a.L];
         const Tw *tw = a.tw + ((size_t)prime << LOGN);
         const PrimeConst *pc = a.pc + prime;
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(256, WPS) void ntt_coop(NttArgs a, CoopArgs c)
             __syncthreads();
             if (tid == 0)
             {
-                __hip_atomic_fetch_add(&c.done[prow], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&c.done[ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         else

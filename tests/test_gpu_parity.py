@@ -350,3 +350,48 @@ def test_config2_shape_properties(moai):
     assert (dl.to_numpy() == ds.to_numpy()).all()
     ctx.ntt_inverse(dx, B * 2, L)
     assert (dx.to_numpy(x.shape) == x).all()
+
+
+def test_empty_and_degenerate_calls(moai, env12):
+    """zero-sized batches are no-ops; L = 1 (last level) works; invalid levels are refused."""
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(21)
+    x = O.uniform_rns(rng, primes[:1], (2,), n)
+    d = up(moai, x)
+    ctx.ntt_forward(d, 0, 1)
+    ctx.add(d, d, d, 0, 1)
+    ctx.switch_key(d, d, d, 1, 0)
+    assert (d.to_numpy(x.shape) == x).all()
+    ctx.ntt_forward(d, 2, 1)
+    assert (d.to_numpy(x.shape) == octx.ntt(x, 1)).all()
+    with pytest.raises(moai.MoaiError):
+        ctx.ntt_forward(d, 1, 1, prime_index=[len(primes)])  # prime index out of range
+    with pytest.raises(moai.MoaiError):
+        ctx.add(d, d, d, 1, len(primes) + 1)  # more rows than the context has primes
+    with pytest.raises(moai.MoaiError):
+        ctx.switch_key(d, d, d, len(primes), 1)  # L exceeds the key's decomposition size
+
+
+def test_coop_single_launch_ntt_agrees(moai):
+    """the opt-in single-launch transform (MOAI_NTT_COOP=1, per-XCD queues) against the oracle"""
+    import subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import oracle as O, __graft_entry__ as g
+m = g.load_package()
+for logn, bits in ((12, [60, 46]), (14, [58, 51, 46]), (16, [60, 51, 46, 58])):
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), m.Context(logn, primes)
+    x = O.uniform_rns(np.random.default_rng(logn), primes, (5,), n)
+    d = m.DeviceBuffer.from_numpy(x)
+    ctx.ntt_forward(d, 5, len(primes)); assert (d.to_numpy(x.shape) == octx.ntt(x, len(primes))).all()
+    ctx.ntt_inverse(d, 5, len(primes)); assert (d.to_numpy(x.shape) == x).all()
+print("ok")
+'''
+    env = dict(os.environ, MOAI_NTT_COOP="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -257,6 +257,54 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
     {
         return rc;
     }
+    if (c->logn >= 12)
+    {
+        // fused: the expand rides on the strided pass's loads, the division on the contiguous pass's stores
+        ModDownArgs a;
+        a.last = last_rows;
+        a.u = u;
+        a.acc = acc;
+        a.out = out;
+        a.tw = c->fwd_tw;
+        a.twb = c->fwd_twb;
+        a.pc = c->pc;
+        a.inv_last = c->inv_qlast + (size_t)prime_last * c->k;
+        a.prime_last = prime_last;
+        a.acc_stride = acc_stride;
+        a.Lout = (uint32_t)Lout;
+        a.P = (uint32_t)P;
+        a.accumulate = accumulate ? 1 : 0;
+        a.total_work = (uint32_t)(P * Lout * (c->n >> 12));
+        bool noguard = true;
+        for (size_t i = 0; i < Lout && noguard; ++i)
+        {
+            noguard = noguard_ok(c->primes[i]);
+        }
+#define MOAI_MD_CASE(LG)                                                                                     \
+    case LG:                                                                                                 \
+        if (noguard)                                                                                         \
+        {                                                                                                    \
+            hipLaunchKernelGGL((moddown_strided<LG, true>), dim3(a.total_work), dim3(256), 0, s, a);         \
+            hipLaunchKernelGGL((moddown_contig<LG, true>), dim3(a.total_work), dim3(256), 0, s, a);          \
+        }                                                                                                    \
+        else                                                                                                 \
+        {                                                                                                    \
+            hipLaunchKernelGGL((moddown_strided<LG, false>), dim3(a.total_work), dim3(256), 0, s, a);        \
+            hipLaunchKernelGGL((moddown_contig<LG, false>), dim3(a.total_work), dim3(256), 0, s, a);         \
+        }                                                                                                    \
+        break;
+        switch (c->logn)
+        {
+            MOAI_MD_CASE(12)
+            MOAI_MD_CASE(13)
+            MOAI_MD_CASE(14)
+            MOAI_MD_CASE(15)
+            MOAI_MD_CASE(16)
+        }
+#undef MOAI_MD_CASE
+        MOAI_LAUNCH_CHECK();
+        return MOAI_OK;
+    }
     ExpandLastArgs e;
     e.last = last_rows;
     e.u = u;

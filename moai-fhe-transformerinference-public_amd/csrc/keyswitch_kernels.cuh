@@ -226,4 +226,103 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
     }
 }
 
+// ---- "divide by the last modulus and round" with its element-wise halves fused into the NTT ---------
+// (RNSTool::divide_and_round_q_last_ntt_inplace SEAL/util/rns.cpp:830-901; key-switch mod-down
+// SEAL/evaluator.cpp:2913-3018).  `last` [P][N] is the dropped row in coefficient form.
+//   strided pass load:   u = ([last + q_last/2] mod q_last) mod q_i + (q_i - (q_last/2 mod q_i))
+//   contiguous pass end: out_i = (acc_i - NTT(u)_i) * q_last^-1 mod q_i   (+ out_i when accumulating)
+struct LoadExpandLast
+{
+    uint64_t ql, half, q, cr1, fix;
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return barrett64(csub(v + half, ql), q, cr1) + fix;
+    }
+};
+
+struct StoreModDown
+{
+    const ulonglong2 *acc; // tile base of the row being divided
+    ulonglong2 *out;       // tile base of the result row
+    uint64_t q;
+    Tw inv;
+    int accumulate;
+    __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 u) const
+    {
+        ulonglong2 x = acc[ch], r;
+        r.x = csub(mul_shoup_lazy(x.x + q - u.x, inv.w, inv.wq, q), q);
+        r.y = csub(mul_shoup_lazy(x.y + q - u.y, inv.w, inv.wq, q), q);
+        if (accumulate)
+        {
+            ulonglong2 c = out[ch];
+            r.x = csub(r.x + c.x, q);
+            r.y = csub(r.y + c.y, q);
+        }
+        out[ch] = r;
+    }
+};
+
+struct ModDownArgs
+{
+    const uint64_t *last; // [P][N] coefficient form, canonical under prime_last
+    uint64_t *u;          // [P][Lout][N] scratch between the two passes
+    const uint64_t *acc;  // row (p, i) at acc + (p * acc_stride + i) * N
+    uint64_t *out;        // [P][Lout][N]
+    const Tw *tw;
+    const Tw *twb;
+    const PrimeConst *pc;
+    const Tw *inv_last;   // q_last^-1 mod q_i
+    uint32_t prime_last;
+    uint32_t acc_stride;
+    uint32_t Lout;
+    uint32_t P;
+    int accumulate;
+    uint32_t total_work;
+};
+
+template <int LOGN, bool NOGUARD>
+__global__ __launch_bounds__(256, 4) void moddown_strided(ModDownArgs a)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ uint64_t lds[4096];
+    // tile fastest, then prime, then polynomial: neighbours read the same `last` row
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t tile = w % TPR;
+    w /= TPR;
+    const uint32_t i = w % a.Lout;
+    const uint32_t p = w / a.Lout;
+    const PrimeConst *pc = a.pc + i;
+    LoadExpandLast op;
+    op.ql = a.pc[a.prime_last].q;
+    op.half = op.ql >> 1;
+    op.q = pc->q;
+    op.cr1 = pc->cr1;
+    op.fix = pc->q - barrett64(op.half, pc->q, pc->cr1);
+    fwd_strided_tile<LOGN, LoadExpandLast, NOGUARD>(a.last + ((size_t)p << LOGN), a.u + (((size_t)p * a.Lout + i) << LOGN), tile,
+                                                    a.tw + ((size_t)i << LOGN), pc->q, pc->q2, lds, threadIdx.x, op);
+}
+
+template <int LOGN, bool NOGUARD>
+__global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    __shared__ ulonglong2 lds2[2048];
+    // polynomial fastest: the workgroups that share a twiddle slice run together
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t p = w % a.P;
+    w /= a.P;
+    const uint32_t tile = w % TPR;
+    const uint32_t i = w / TPR;
+    const PrimeConst *pc = a.pc + i;
+    StoreModDown st;
+    st.acc = reinterpret_cast<const ulonglong2 *>(a.acc + (((size_t)p * a.acc_stride + i) << LOGN)) + ((size_t)tile << 11);
+    st.out = reinterpret_cast<ulonglong2 *>(a.out + (((size_t)p * a.Lout + i) << LOGN)) + ((size_t)tile << 11);
+    st.q = pc->q;
+    st.inv = a.inv_last[i];
+    st.accumulate = a.accumulate;
+    fwd_contig_tile<LOGN, NOGUARD, StoreModDown>(a.u + (((size_t)p * a.Lout + i) << LOGN), tile, a.tw + ((size_t)i << LOGN), pc->q,
+                                                 pc->q2, lds2, threadIdx.x, a.twb + (size_t)i * ((size_t)TPR * 15 * 256),
+                                                 pc->cr1, st);
+}
+
 } // namespace moai

@@ -190,12 +190,22 @@ __global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
 // =====================================================================================================
 // forward, contiguous pass: stages LOGN-8 .. LOGN-1 on 16 consecutive 256-blocks; writes canonical
 // =====================================================================================================
+// what the contiguous pass does with a finished 16-byte chunk (index ch within the 4096-coefficient tile)
+struct StoreTile
+{
+    ulonglong2 *out; // tile base
+    __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 v) const
+    {
+        out[ch] = v;
+    }
+};
+
 // NOGUARD: input below 20q (strided pass without guards), stages without guards, one Barrett step at
 // the end (cr1 = high word of floor(2^128/q)); otherwise the reference's [0,4q) discipline
-template <int LOGN, bool NOGUARD = false>
+template <int LOGN, bool NOGUARD = false, class StoreOp = StoreTile>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
-                                                const Tw *__restrict__ twb, uint64_t cr1 = 0)
+                                                const Tw *__restrict__ twb, uint64_t cr1, StoreOp store)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
@@ -272,14 +282,23 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
         lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
     }
     __syncthreads();
-    ulonglong2 *__restrict__ out2 = reinterpret_cast<ulonglong2 *>(base);
 #pragma unroll
     for (int it = 0; it < 8; ++it)
     {
         uint32_t ch = (uint32_t)it * 256u + tid;
         uint32_t rr = ch >> 3;
-        out2[ch] = lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))];
+        store(ch, lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))]);
     }
+}
+
+template <int LOGN, bool NOGUARD = false>
+__device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
+                                                uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
+                                                const Tw *__restrict__ twb, uint64_t cr1 = 0)
+{
+    StoreTile st;
+    st.out = reinterpret_cast<ulonglong2 *>(rowp + ((size_t)tile << 12));
+    fwd_contig_tile<LOGN, NOGUARD, StoreTile>(rowp, tile, tw, q, q2, lds2, tid, twb, cr1, st);
 }
 
 template <int LOGN, bool NOGUARD = false>

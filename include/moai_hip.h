@@ -131,6 +131,17 @@ int moai_ct_multiply(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64
 /* Evaluator::ckks_square SEAL/evaluator.cpp:1223-1282: (x0^2, 2 x0 x1, x1^2) */
 int moai_ct_square(moai_ctx *ctx, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream);
 
+/*
+ * Column-packed ciphertext x plaintext matrix product with scalar-encoded weights: the body of
+ * ct_pt_matrix_mul_wo_pre (include/source/matrix_mul/Ct_pt_matrix_mul.hpp:4-49, :51-101) before its
+ * rescale, i.e. out[c] = sum_j multiply_plain(X[j], encode(W[j][c])) for every output column c.
+ * x: [rows][size][L][N]; w: DEVICE array uint64[L][rows][cols], w[r][j][c] = the residue under prime r
+ * of the scalar plaintext CKKSEncoder::encode(W[j][c], scale) (SEAL/ckks.cpp:101-150), canonical;
+ * out: [cols][size][L][N] (must not alias x).  Follow with moai_rescale(out, ..., batch = cols).
+ */
+int moai_ct_pt_matmul(moai_ctx *ctx, const uint64_t *x, const uint64_t *w, uint64_t *out, size_t rows, size_t cols,
+                      size_t size, size_t L, void *stream);
+
 /* ---- level changes ---------------------------------------------------------------------------------
  * Evaluator::rescale_to_next SEAL/evaluator.cpp:1682-1720 -> mod_switch_scale_to_next :1402-1481 ->
  * RNSTool::divide_and_round_q_last_ntt_inplace SEAL/util/rns.cpp:830-901.

@@ -215,6 +215,92 @@ __global__ void galois_table_kernel(uint32_t *table, int logn, uint32_t elt)
     }
 }
 
+
+// ---- column-packed ciphertext x plaintext-matrix product with scalar weights --------------------------
+// include/source/matrix_mul/Ct_pt_matrix_mul.hpp:4-49 computes, per output column c,
+//     out[c] = sum_j multiply_plain(X[j], encode(W[j][c]))          (then one rescale)
+// as rows*cols separate multiply_plain + add_inplace calls.  The scalar plaintexts have constant rows
+// (SEAL/ckks.cpp:131-150), so the whole product is, per (polynomial, prime, coefficient),
+//     out[c] = sum_j X[j] * w[j][c] mod q          with one scalar w per (j, c, prime).
+// One workgroup column handles CG output columns at once: every loaded coefficient of X[j] feeds CG
+// 128-bit accumulators (weights are wave-uniform scalars), reduced with one Barrett step every 32 terms
+// and at the end.  X is streamed cols/CG times instead of cols times; the kernel is VALU-bound.
+struct MatmulArgs
+{
+    const uint64_t *x;   // [rows][size][L][N]
+    const uint64_t *w;   // [L][rows][cols] canonical scalar residues under prime r
+    uint64_t *out;       // [cols][size][L][N]
+    const PrimeConst *pc;
+    uint32_t rows, cols, size, L, n2;
+};
+
+template <int CG>
+__global__ __launch_bounds__(256) void ct_pt_matmul_kernel(MatmulArgs g)
+{
+    const uint32_t pr = blockIdx.y;            // p * L + r
+    const uint32_t r = pr % g.L;
+    const uint32_t c0 = blockIdx.z * CG;
+    const PrimeConst *pc = g.pc + r;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.n2)
+    {
+        return;
+    }
+    const size_t poly_stride = (size_t)g.size * g.L * g.n2; // chunks per input ciphertext
+    const ulonglong2 *__restrict__ x2 = reinterpret_cast<const ulonglong2 *>(g.x) + (size_t)pr * g.n2 + i;
+    const uint64_t *__restrict__ wr = g.w + (size_t)r * g.rows * g.cols + c0;
+    uint64_t lox[CG], hix[CG], loy[CG], hiy[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+    {
+        lox[c] = hix[c] = loy[c] = hiy[c] = 0;
+    }
+    for (uint32_t j = 0; j < g.rows; ++j)
+    {
+        const ulonglong2 v = x2[(size_t)j * poly_stride];
+        const uint64_t *__restrict__ wj = wr + (size_t)j * g.cols;
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+        {
+            if (c0 + c < g.cols)
+            {
+                const uint64_t wv = wj[c];
+                uint64_t pl = v.x * wv, ph = mulhi64(v.x, wv);
+                lox[c] += pl;
+                hix[c] += ph + (lox[c] < pl ? 1 : 0);
+                pl = v.y * wv;
+                ph = mulhi64(v.y, wv);
+                loy[c] += pl;
+                hiy[c] += ph + (loy[c] < pl ? 1 : 0);
+            }
+        }
+        if ((j & 31u) == 31u)
+        {
+            // 32 products below 2^122 each: fold back below q before the accumulator can overflow
+#pragma unroll
+            for (int c = 0; c < CG; ++c)
+            {
+                lox[c] = barrett128(lox[c], hix[c], q, cr0, cr1);
+                hix[c] = 0;
+                loy[c] = barrett128(loy[c], hiy[c], q, cr0, cr1);
+                hiy[c] = 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+    {
+        if (c0 + c < g.cols)
+        {
+            ulonglong2 o;
+            o.x = barrett128(lox[c], hix[c], q, cr0, cr1);
+            o.y = barrett128(loy[c], hiy[c], q, cr0, cr1);
+            reinterpret_cast<ulonglong2 *>(g.out)[((size_t)(c0 + c) * g.size * g.L + pr) * g.n2 + i] = o;
+        }
+    }
+}
+
 static inline dim3 row_grid(const moai_ctx *c, size_t rows, uint32_t per_thread_chunks = 1)
 {
     uint32_t n2 = (uint32_t)(c->n >> 1);
@@ -541,4 +627,41 @@ extern "C" uint32_t moai_galois_elt_from_step(const moai_ctx *c, int step)
         e = (e * 5) & (m - 1);
     }
     return (uint32_t)e;
+}
+
+extern "C" int moai_ct_pt_matmul(moai_ctx *c, const uint64_t *x, const uint64_t *w, uint64_t *out, size_t rows,
+                                 size_t cols, size_t size, size_t L, void *stream)
+{
+    int rc = check_rows(c, (rows > cols ? rows : cols) * size, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (rows == 0 || cols == 0 || size == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!x || !w || !out || x == out)
+    {
+        return set_error(MOAI_EINVAL, "bad pointers");
+    }
+    constexpr int CG = 16;
+    if (size * L > 65535 || (cols + CG - 1) / CG > 65535)
+    {
+        return set_error(MOAI_EINVAL, "matrix too large for one launch");
+    }
+    MatmulArgs g;
+    g.x = x;
+    g.w = w;
+    g.out = out;
+    g.pc = c->pc;
+    g.rows = (uint32_t)rows;
+    g.cols = (uint32_t)cols;
+    g.size = (uint32_t)size;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    dim3 grid((g.n2 + 255u) / 256u, (uint32_t)(size * L), (uint32_t)((cols + CG - 1) / CG));
+    hipLaunchKernelGGL(ct_pt_matmul_kernel<CG>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
 }

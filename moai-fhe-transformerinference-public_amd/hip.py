@@ -46,6 +46,7 @@ SYMBOLS = {
     "moai_add_scalar_rows": (C.c_int, [vp, vp, u64p, vp, sz, sz, vp]),
     "moai_ct_multiply": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_square": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
     "moai_mod_drop": (C.c_int, [vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_galois_permute": (C.c_int, [vp, vp, vp, sz, sz, C.c_uint32, vp]),
@@ -215,6 +216,9 @@ class Context:
 
     def ct_square(self, x, out, L, batch, stream=None):
         _check(lib().moai_ct_square(self.h, _ptr(x), _ptr(out), L, batch, stream))
+
+    def ct_pt_matmul(self, x, w, out, rows, cols, size, L, stream=None):
+        _check(lib().moai_ct_pt_matmul(self.h, _ptr(x), _ptr(w), _ptr(out), rows, cols, size, L, stream))
 
     def rescale(self, src, out, size, L, batch, stream=None):
         _check(lib().moai_rescale(self.h, _ptr(src), _ptr(out), size, L, batch, stream))

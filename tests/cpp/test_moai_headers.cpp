@@ -21,6 +21,8 @@
 #include "Ct_ct_matrix_mul.hpp"
 #include "gelu_others.hpp"
 
+#include "seal/moai_fused.h"
+
 static int g_fail = 0;
 #define CHECK(cond)                                                        \
     do                                                                     \
@@ -94,6 +96,18 @@ int main()
         CHECK(err < 1e-4);
         CHECK(context.get_context_data(Y[c].parms_id())->chain_index() ==
               context.get_context_data(enc_X[0].parms_id())->chain_index() - 1);
+    }
+
+    // ---- the fused replacement must produce the very same ciphertexts as MOAI's loop -----------------
+    {
+        vector<Ciphertext> Yf = moai_fused::ct_pt_matrix_mul_wo_pre(enc_X, W, num_col, col_W, num_col, context);
+        CHECK(Yf.size() == Y.size());
+        for (int c = 0; c < col_W; c++)
+        {
+            CHECK(Yf[c].parms_id() == Y[c].parms_id());
+            CHECK(Yf[c].scale() == Y[c].scale());
+            CHECK(Yf[c].download() == Y[c].download());
+        }
     }
 
     // ---- ct_ct_matrix_mul_colpacking ------------------------------------------------------------------

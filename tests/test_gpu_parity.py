@@ -395,3 +395,31 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("bits,rows,cols", [([51, 46, 46, 58], 70, 19), ([60, 61, 60], 33, 5), ([46, 51], 3, 16)])
+def test_ct_pt_matmul_matches_multiply_plain_loop(moai, bits, rows, cols):
+    """moai_ct_pt_matmul == the reference loop of multiply_plain(scalar plaintext) + add_inplace
+    (Ct_pt_matrix_mul.hpp:19-38), including the 32-term accumulator folds and ragged column groups."""
+    logn = 12
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    L = len(primes) - 1
+    rng = np.random.default_rng(rows * cols)
+    x = O.uniform_rns(rng, primes[:L], (rows, 2), n)
+    w = np.empty((L, rows, cols), dtype=np.uint64)
+    for r in range(L):
+        w[r] = rng.integers(0, primes[r], size=(rows, cols), dtype=np.uint64)
+    w[:, 0, 0] = [q - 1 for q in primes[:L]]
+    x[0, :, :, :8] = np.array([q - 1 for q in primes[:L]], dtype=np.uint64)[None, :, None]
+    dx, dw = up(moai, x), up(moai, w)
+    dout = moai.DeviceBuffer(cols * 2 * L * n)
+    ctx.ct_pt_matmul(dx, dw, dout, rows, cols, 2, L)
+    got = dout.to_numpy((cols, 2, L, n))
+    for c in (0, cols // 2, cols - 1):
+        acc = np.zeros((2, L, n), dtype=np.uint64)
+        for j in range(rows):
+            pt = np.stack([np.full(n, w[r, j, c], dtype=np.uint64) for r in range(L)])
+            acc = octx.add(acc, octx.multiply_plain(x[j], 2, L, pt), 2, L)
+        assert (got[c] == acc).all(), c

@@ -74,6 +74,13 @@ struct KsP2Args
     uint32_t total_work;
 };
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its
+// outstanding global loads (a __syncthreads() would drain vmcnt as well and serialise the prefetch below).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void mac128r(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
 {
     uint64_t pl = a * b;
@@ -115,15 +122,17 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
         lo0[e] = hi0[e] = lo1[e] = hi1[e] = 0;
     }
 
+    // software pipeline: digit J+1 is loaded into the (then dead) coefficient registers while digit J is
+    // being multiplied into the accumulators
+    const uint64_t *__restrict__ dig = a.tmp + ((((size_t)bq * a.G + g) * a.L) << LOGN) + ((size_t)tile << 12);
+    uint64_t x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+    {
+        x[j] = dig[(b << 8) | ((uint32_t)j << 4) | tl];
+    }
     for (uint32_t J = 0; J < a.L; ++J)
     {
-        const uint64_t *__restrict__ base = a.tmp + ((((size_t)bq * a.G + g) * a.L + J) << LOGN) + ((size_t)tile << 12);
-        uint64_t x[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-        {
-            x[j] = base[(b << 8) | ((uint32_t)j << 4) | tl];
-        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
         {
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
         {
             lds[phys_contig((b << 8) | ((uint32_t)j << 4) | tl)] = x[j];
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int c = 0; c < 8; ++c)
         {
@@ -186,7 +195,16 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
             }
             lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
         }
-        __syncthreads();
+        if (J + 1 < a.L)
+        {
+            const uint64_t *__restrict__ nxt = dig + ((size_t)(J + 1) << LOGN);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+            {
+                x[j] = nxt[(b << 8) | ((uint32_t)j << 4) | tl];
+            }
+        }
+        lds_barrier();
         // coalesced view of the tile: chunk ch = it * 256 + tid; multiply into both key components
         const ulonglong2 *__restrict__ k0 =
             reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 11);
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
             mac128r(lo1[2 * it], hi1[2 * it], v.x, kb.x);
             mac128r(lo1[2 * it + 1], hi1[2 * it + 1], v.y, kb.y);
         }
-        __syncthreads(); // the tile is dead: the next digit may overwrite it
+        lds_barrier(); // the tile is dead: the next digit may overwrite it
     }
     const uint64_t cr0 = pc->cr0, cr1 = pc->cr1;
     ulonglong2 *__restrict__ o0 =

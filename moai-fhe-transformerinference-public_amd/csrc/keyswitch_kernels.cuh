@@ -74,13 +74,6 @@ struct KsP2Args
     uint32_t total_work;
 };
 
-// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its
-// outstanding global loads (a __syncthreads() would drain vmcnt as well and serialise the prefetch below).
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ void mac128r(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
 {
     uint64_t pl = a * b;

@@ -33,6 +33,13 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total)
     return (b & 7u) * (total >> 3) + (b >> 3);
 }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its
+// outstanding global loads (a __syncthreads() would drain vmcnt as well and serialise the prefetch below).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- LDS tile layouts ------------------------------------------------------------------------------
 // contiguous pass: element e of the 4096-tile lives in 16-byte chunk (e>>1); chunks are XOR-swizzled
 // within each 128-byte row so that "one row per lane" (ds_*_b128) and "one column per lane"

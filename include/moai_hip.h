@@ -59,6 +59,8 @@ int moai_version(void);
 int moai_ctx_create(int coeff_count_power, const uint64_t *primes, size_t k, int device, moai_ctx **out);
 void moai_ctx_destroy(moai_ctx *ctx);
 int moai_ctx_reserve(moai_ctx *ctx, size_t workspace_bytes); /* arena of the default (NULL) stream */
+/* arena of `stream`: call before capturing that stream into a hipGraph (arenas never grow under capture) */
+int moai_ctx_reserve_stream(moai_ctx *ctx, void *stream, size_t workspace_bytes);
 size_t moai_ctx_coeff_count(const moai_ctx *ctx);
 size_t moai_ctx_prime_count(const moai_ctx *ctx);
 /* psi = minimal primitive 2N-th root of prime i (NTTTables::get_root) */

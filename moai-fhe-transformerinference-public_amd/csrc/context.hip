@@ -428,6 +428,15 @@ extern "C" int moai_ctx_reserve(moai_ctx *c, size_t bytes)
     return moai::reserve_for_stream(c, nullptr, bytes, nullptr);
 }
 
+extern "C" int moai_ctx_reserve_stream(moai_ctx *c, void *stream, size_t bytes)
+{
+    if (!c)
+    {
+        return set_error(MOAI_EINVAL, "null context");
+    }
+    return moai::reserve_for_stream(c, stream, bytes, nullptr);
+}
+
 extern "C" size_t moai_ctx_coeff_count(const moai_ctx *c)
 {
     return c ? c->n : 0;

@@ -24,6 +24,7 @@ SYMBOLS = {
     "moai_ctx_create": (C.c_int, [C.c_int, u64p, sz, C.c_int, C.POINTER(vp)]),
     "moai_ctx_destroy": (None, [vp]),
     "moai_ctx_reserve": (C.c_int, [vp, sz]),
+    "moai_ctx_reserve_stream": (C.c_int, [vp, vp, sz]),
     "moai_ctx_coeff_count": (sz, [vp]),
     "moai_ctx_prime_count": (sz, [vp]),
     "moai_ctx_root": (C.c_uint64, [vp, sz]),
@@ -172,8 +173,11 @@ class Context:
         except Exception:
             pass
 
-    def reserve(self, nbytes):
-        _check(lib().moai_ctx_reserve(self.h, int(nbytes)))
+    def reserve(self, nbytes, stream=None):
+        if stream is None:
+            _check(lib().moai_ctx_reserve(self.h, int(nbytes)))
+        else:
+            _check(lib().moai_ctx_reserve_stream(self.h, stream, int(nbytes)))
 
     def root(self, i):
         return int(lib().moai_ctx_root(self.h, i))

@@ -423,3 +423,35 @@ def test_ct_pt_matmul_matches_multiply_plain_loop(moai, bits, rows, cols):
             pt = np.stack([np.full(n, w[r, j, c], dtype=np.uint64) for r in range(L)])
             acc = octx.add(acc, octx.multiply_plain(x[j], 2, L, pt), 2, L)
         assert (got[c] == acc).all(), c
+
+
+def test_key_switch_replays_from_a_hip_graph(moai):
+    """the ~80 launches of one rotate captured once into a hipGraph (through torch's capture API, which
+    is plumbing here) and replayed on new data: same bits as the oracle, one launch per call."""
+    torch = pytest.importorskip("torch")
+    logn = 13
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, [51, 46, 46, 46, 58])
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k, L = len(primes), 4
+    rng = np.random.default_rng(5)
+    key = O.uniform_rns(rng, primes, (k - 1, 2), n)
+    dkey = up(moai, key)
+    elt = ctx.galois_elt_from_step(1)
+    ct_static = torch.zeros((2, L, n), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        # warm-up on the capture stream: builds the Galois table and sizes this stream's arena
+        ctx.apply_galois(ct_static.data_ptr(), L, elt, dkey, 1, stream=side.cuda_stream)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        ctx.apply_galois(ct_static.data_ptr(), L, elt, dkey, 1, stream=torch.cuda.current_stream().cuda_stream)
+    for seed in (1, 2):
+        ct = O.uniform_rns(np.random.default_rng(seed), primes[:L], (2,), n)
+        ct_static.copy_(torch.from_numpy(ct.view(np.int64)))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = ct_static.cpu().numpy().view(np.uint64)
+        assert (got == octx.apply_galois(ct, L, elt, key).reshape(2, L, n)).all()

@@ -45,6 +45,27 @@ for L, B in [(35, 1), (35, 8), (35, 64), (21, 64), (15, 64), (3, 64), (35, 256)]
     del ct
 
 
+# one ciphertext per call replayed from a hipGraph (captured through torch's capture API)
+if "--graph" in sys.argv:
+    for L in (35, 21, 3):
+        ct = torch.randint(0, 1 << 45, (1, 2, L, N), dtype=torch.int64, device=dev)
+        elt = ctx.galois_elt_from_step(1)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ctx.apply_galois(ct.data_ptr(), L, elt, key.data_ptr(), 1, stream=side.cuda_stream)
+        side.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            ctx.apply_galois(ct.data_ptr(), L, elt, key.data_ptr(), 1, stream=torch.cuda.current_stream().cuda_stream)
+        gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gr.replay()
+        torch.cuda.synchronize()
+        print("L=%2d batch=  1 replayed from a hipGraph: %9.3f ms per call" % (L, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
+
 # CPU baseline for the same operation: the oracle's restatement of SEAL's switch_key_inplace
 # (SEAL/evaluator.cpp:2724-3020) at MOAI parameters, OpenMP over ciphertexts like MOAI's loops
 if "--cpu" in sys.argv:

@@ -202,7 +202,7 @@ namespace seal
             }
             else
             {
-                util::DeviceArray tmp(L * n);
+                util::DeviceArray tmp(L * n, context_.stream());
                 util::hip_check(moai_memcpy_d2d(tmp.get(), plain.device_data(), L * n * 8, context_.stream()));
                 util::hip_check(moai_ntt_inverse(context_.device(), tmp.get(), 1, L, nullptr, context_.stream()));
                 util::hip_check(moai_memcpy_d2h(rns.data(), tmp.get(), L * n * 8, context_.stream()));
@@ -357,7 +357,7 @@ namespace seal
             destination.n_ = n;
             destination.L_ = L;
             destination.stream_ = context_.stream();
-            destination.data_.resize(L * n);
+            destination.data_.resize(L * n, context_.stream());
             util::hip_check(moai_memcpy_h2d(destination.data_.get(), rns.data(), L * n * 8, context_.stream()));
             context_.sync(); // rns is a stack-owned buffer
             util::hip_check(moai_ntt_forward(context_.device(), destination.data_.get(), 1, L, nullptr, context_.stream()));
@@ -518,7 +518,7 @@ namespace seal
             util::sample_ternary(n_, kp.secret_key_hamming_weight(), s);
             std::vector<std::uint64_t> rns;
             util::to_rns(s, primes_, rns);
-            sk_.ntt_ = std::make_shared<util::DeviceArray>(k_ * n_);
+            sk_.ntt_ = std::make_shared<util::DeviceArray>(k_ * n_, context_.stream());
             upload_ntt(rns, *sk_.ntt_, k_);
             sk_.parms_id_ = context_.key_parms_id();
         }
@@ -540,7 +540,7 @@ namespace seal
             {
                 throw std::logic_error("keyswitching is not supported by the context");
             }
-            util::DeviceArray s2(k_ * n_);
+            util::DeviceArray s2(k_ * n_, context_.stream());
             util::hip_check(moai_dyadic_mul(context_.device(), sk_.ntt_->get(), sk_.ntt_->get(), s2.get(), 1, 1, k_,
                                             context_.stream()));
             destination.keys_.assign(1, nullptr);
@@ -556,7 +556,7 @@ namespace seal
                 throw std::logic_error("keyswitching is not supported by the context");
             }
             destination.keys_.assign(n_, nullptr);
-            util::DeviceArray rotated(k_ * n_);
+            util::DeviceArray rotated(k_ * n_, context_.stream());
             for (std::uint32_t elt : galois_elts)
             {
                 if (!(elt & 1) || elt >= 2 * n_)
@@ -636,7 +636,7 @@ namespace seal
             util::hip_check(moai_memcpy_h2d(c0, e_rns.data(), k_ * n_ * 8, context_.stream()));
             context_.sync();
             util::hip_check(moai_ntt_forward(context_.device(), c0, 1, k_, nullptr, context_.stream()));
-            util::DeviceArray as(k_ * n_);
+            util::DeviceArray as(k_ * n_, context_.stream());
             util::hip_check(moai_dyadic_mul(context_.device(), c1, sk_.ntt_->get(), as.get(), 1, 1, k_, context_.stream()));
             util::hip_check(moai_sub(context_.device(), c0, as.get(), c0, 1, k_, context_.stream()));
             context_.sync();
@@ -645,8 +645,8 @@ namespace seal
         std::shared_ptr<util::DeviceArray> make_kswitch_key(const std::uint64_t *new_key_ntt) const
         {
             const std::size_t digits = k_ - 1;
-            auto key = std::make_shared<util::DeviceArray>(digits * 2 * k_ * n_);
-            util::DeviceArray scaled(k_ * n_);
+            auto key = std::make_shared<util::DeviceArray>(digits * 2 * k_ * n_, context_.stream());
+            util::DeviceArray scaled(k_ * n_, context_.stream());
             std::vector<std::uint64_t> factor(k_, 0);
             for (std::size_t j = 0; j < k_; j++)
             {
@@ -655,7 +655,7 @@ namespace seal
             util::hip_check(moai_mul_scalar_rows(context_.device(), new_key_ntt, factor.data(), scaled.get(), 1, k_,
                                                  context_.stream()));
             // addend [k][N]: zero except row J = (p mod q_J) * new_key[J]
-            util::DeviceArray sparse(k_ * n_);
+            util::DeviceArray sparse(k_ * n_, context_.stream());
             util::hip_check(moai_memset_zero(sparse.get(), k_ * n_ * 8, context_.stream()));
             for (std::size_t J = 0; J < digits; J++)
             {
@@ -740,14 +740,14 @@ namespace seal
             std::copy(tmp.begin(), tmp.end(), e_rns.begin());
             util::to_rns(e1, primes, tmp);
             std::copy(tmp.begin(), tmp.end(), e_rns.begin() + static_cast<std::ptrdiff_t>(L * n));
-            util::DeviceArray du(L * n);
+            util::DeviceArray du(L * n, context_.stream());
             util::hip_check(moai_memcpy_h2d(du.get(), u_rns.data(), L * n * 8, context_.stream()));
             util::hip_check(moai_memcpy_h2d(destination.device_data(), e_rns.data(), 2 * L * n * 8, context_.stream()));
             context_.sync();
             util::hip_check(moai_ntt_forward(context_.device(), du.get(), 1, L, nullptr, context_.stream()));
             util::hip_check(moai_ntt_forward(context_.device(), destination.device_data(), 2, L, nullptr, context_.stream()));
             // c_i = pk_i * u + e_i over the first L primes of the key-level public key
-            util::DeviceArray prod(L * n);
+            util::DeviceArray prod(L * n, context_.stream());
             for (int i = 0; i < 2; i++)
             {
                 const std::uint64_t *pk_poly = pk_.device_data() + static_cast<std::size_t>(i) * k * n;
@@ -791,10 +791,10 @@ namespace seal
             destination.n_ = n;
             destination.L_ = L;
             destination.stream_ = context_.stream();
-            destination.data_.resize(L * n);
+            destination.data_.resize(L * n, context_.stream());
             std::uint64_t *acc = destination.data_.get();
             const std::uint64_t *ct = encrypted.device_data();
-            util::DeviceArray spow(L * n), term(L * n);
+            util::DeviceArray spow(L * n, context_.stream()), term(L * n, context_.stream());
             util::hip_check(moai_memcpy_d2d(acc, ct, L * n * 8, context_.stream()));
             util::hip_check(moai_memcpy_d2d(spow.get(), sk_->get(), L * n * 8, context_.stream()));
             for (std::size_t p = 1; p < encrypted.size(); p++)

@@ -34,8 +34,15 @@ namespace seal
         }
         void negate(const Ciphertext &encrypted, Ciphertext &destination) const
         {
-            destination = encrypted;
-            negate_inplace(destination);
+            if (&encrypted == &destination)
+            {
+                negate_inplace(destination);
+                return;
+            }
+            check_ct(encrypted, "encrypted");
+            like(destination, encrypted);
+            hip(moai_negate(dev(), encrypted.device_data(), destination.device_data(), encrypted.size(),
+                            encrypted.coeff_modulus_size(), st()));
         }
         void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
         {
@@ -366,7 +373,13 @@ namespace seal
         void multiply_plain_inplace(Ciphertext &encrypted, const Plaintext &plain,
                                     MemoryPoolHandle = MemoryPoolHandle()) const
         {
-            // SEAL/evaluator.cpp:2154-2198 -> multiply_plain_ntt :2336-2373
+            multiply_plain(encrypted, plain, encrypted);
+        }
+        void multiply_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination,
+                            MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            // SEAL/evaluator.cpp:2154-2198 -> multiply_plain_ntt :2336-2373; the product is written straight
+            // into `destination` (no deep copy of the input first)
             check_ct(encrypted, "encrypted");
             if (!plain.is_ntt_form() || !encrypted.is_ntt_form())
             {
@@ -383,23 +396,21 @@ namespace seal
                 throw std::invalid_argument("scale out of bounds");
             }
             const std::size_t L = encrypted.coeff_modulus_size();
+            if (&destination != &encrypted)
+            {
+                like(destination, encrypted);
+            }
             if (plain.is_scalar())
             {
-                hip(moai_mul_scalar_rows(dev(), encrypted.device_data(), plain.scalar_rows().data(), encrypted.device_data(),
-                                         encrypted.size(), L, st()));
+                hip(moai_mul_scalar_rows(dev(), encrypted.device_data(), plain.scalar_rows().data(),
+                                         destination.device_data(), encrypted.size(), L, st()));
             }
             else
             {
-                hip(moai_dyadic_mul(dev(), encrypted.device_data(), plain.device_data(), encrypted.device_data(),
+                hip(moai_dyadic_mul(dev(), encrypted.device_data(), plain.device_data(), destination.device_data(),
                                     encrypted.size(), 1, L, st()));
             }
-            encrypted.scale() = new_scale;
-        }
-        void multiply_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination,
-                            MemoryPoolHandle = MemoryPoolHandle()) const
-        {
-            destination = encrypted;
-            multiply_plain_inplace(destination, plain);
+            destination.scale() = new_scale;
         }
 
         // ---- NTT form ---------------------------------------------------------------------------------------------
@@ -602,6 +613,13 @@ namespace seal
             // is_scale_within_bounds, SEAL/evaluator.cpp:29-48
             int bound = cd.total_coeff_modulus_bit_count();
             return !(scale <= 0 || (static_cast<int>(std::log2(scale)) >= bound));
+        }
+        // give `dst` the shape and metadata of `src` without copying residues
+        void like(Ciphertext &dst, const Ciphertext &src) const
+        {
+            dst.resize(context_, src.parms_id(), src.size());
+            dst.is_ntt_form() = src.is_ntt_form();
+            dst.scale() = src.scale();
         }
         void check_ct(const Ciphertext &c, const char *name) const
         {

@@ -53,7 +53,7 @@ namespace moai_fused
             }
         }
         void *st = seal_context.stream();
-        util::DeviceArray dw(w.size()), dx(rows * 2 * L * n), dout(cols * 2 * L * n), dres(cols * 2 * (L - 1) * n);
+        util::DeviceArray dw(w.size(), st), dx(rows * 2 * L * n, st), dout(cols * 2 * L * n, st), dres(cols * 2 * (L - 1) * n, st);
         util::hip_check(moai_memcpy_h2d(dw.get(), w.data(), w.size() * 8, st));
         for (std::size_t j = 0; j < rows; j++)
         {

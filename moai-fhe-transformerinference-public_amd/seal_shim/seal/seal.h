@@ -25,6 +25,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -225,14 +226,92 @@ namespace seal
             return res;
         }
 
+        // Stream-ordered cache of device blocks behind DeviceArray (the role of SEAL's MemoryPoolMT,
+        // SEAL/util/mempool.h:228).  A released block may be handed to a later request of the same size on the
+        // SAME stream only: everything that touched it was enqueued on that stream before the release, so stream
+        // order makes the reuse safe without synchronising, and hipFree's implicit device sync is avoided.
+        class DevicePool
+        {
+        public:
+            static DevicePool &instance()
+            {
+                static DevicePool p;
+                return p;
+            }
+            void *acquire(std::size_t bytes, void *stream)
+            {
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    auto it = free_.find({ stream, bytes });
+                    if (it != free_.end() && !it->second.empty())
+                    {
+                        void *p = it->second.back();
+                        it->second.pop_back();
+                        cached_ -= bytes;
+                        return p;
+                    }
+                }
+                void *p = nullptr;
+                int rc = moai_malloc(&p, bytes);
+                if (rc != MOAI_OK)
+                {
+                    trim(); // give cached blocks back and retry once
+                    hip_check(moai_malloc(&p, bytes));
+                }
+                return p;
+            }
+            void release(void *p, std::size_t bytes, void *stream)
+            {
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    if (cached_ + bytes <= cap_)
+                    {
+                        free_[{ stream, bytes }].push_back(p);
+                        cached_ += bytes;
+                        return;
+                    }
+                }
+                moai_free(p);
+            }
+            void trim()
+            {
+                std::map<std::pair<void *, std::size_t>, std::vector<void *>> old;
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    old.swap(free_);
+                    cached_ = 0;
+                }
+                for (auto &kv : old)
+                {
+                    for (void *p : kv.second)
+                    {
+                        moai_free(p);
+                    }
+                }
+            }
+            // cached blocks are deliberately not returned at static destruction: the HIP runtime may already be
+            // gone by then, and the process is exiting anyway
+            ~DevicePool() = default;
+
+        private:
+            DevicePool()
+            {
+                const char *e = std::getenv("MOAI_POOL_CACHE_MB");
+                cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(65536)) << 20;
+            }
+            std::mutex mu_;
+            std::map<std::pair<void *, std::size_t>, std::vector<void *>> free_;
+            std::size_t cached_ = 0, cap_ = 0;
+        };
+
         // RAII device buffer of uint64 words
         class DeviceArray
         {
         public:
             DeviceArray() = default;
-            explicit DeviceArray(std::size_t words)
+            explicit DeviceArray(std::size_t words, void *stream = nullptr)
             {
-                resize(words);
+                resize(words, stream);
             }
             ~DeviceArray()
             {
@@ -240,7 +319,7 @@ namespace seal
             }
             DeviceArray(const DeviceArray &o) = delete;
             DeviceArray &operator=(const DeviceArray &o) = delete;
-            DeviceArray(DeviceArray &&o) noexcept : ptr_(o.ptr_), words_(o.words_), cap_(o.cap_)
+            DeviceArray(DeviceArray &&o) noexcept : ptr_(o.ptr_), words_(o.words_), cap_(o.cap_), stream_(o.stream_)
             {
                 o.ptr_ = nullptr;
                 o.words_ = o.cap_ = 0;
@@ -253,6 +332,7 @@ namespace seal
                     ptr_ = o.ptr_;
                     words_ = o.words_;
                     cap_ = o.cap_;
+                    stream_ = o.stream_;
                     o.ptr_ = nullptr;
                     o.words_ = o.cap_ = 0;
                 }
@@ -262,7 +342,7 @@ namespace seal
             {
                 if (ptr_)
                 {
-                    moai_free(ptr_);
+                    DevicePool::instance().release(ptr_, cap_ * sizeof(std::uint64_t), stream_);
                 }
                 ptr_ = nullptr;
                 words_ = cap_ = 0;
@@ -275,20 +355,24 @@ namespace seal
                     words_ = words;
                     return;
                 }
-                void *p = nullptr;
-                hip_check(moai_malloc(&p, words * sizeof(std::uint64_t)));
+                void *p = DevicePool::instance().acquire(words * sizeof(std::uint64_t), stream);
                 if (ptr_ && words_)
                 {
+                    // ordered on `stream`; the old block goes back to the pool of its own stream and can only
+                    // be reused behind this copy when both are the same stream, so drain in the other case
                     hip_check(moai_memcpy_d2d(p, ptr_, words_ * sizeof(std::uint64_t), stream));
-                    // the old block may only be freed once the copy has run
-                    hip_check(moai_stream_sync(stream));
+                    if (stream != stream_)
+                    {
+                        hip_check(moai_stream_sync(stream));
+                    }
                 }
                 if (ptr_)
                 {
-                    moai_free(ptr_);
+                    DevicePool::instance().release(ptr_, cap_ * sizeof(std::uint64_t), stream_);
                 }
                 ptr_ = static_cast<std::uint64_t *>(p);
                 words_ = cap_ = words;
+                stream_ = stream;
             }
             std::uint64_t *get() const
             {
@@ -303,6 +387,7 @@ namespace seal
             std::uint64_t *ptr_ = nullptr;
             std::size_t words_ = 0;
             std::size_t cap_ = 0;
+            void *stream_ = nullptr;
         };
     } // namespace util
 
@@ -740,7 +825,7 @@ namespace seal
             L_ = o.L_;
             scalar_rows_ = o.scalar_rows_;
             stream_ = o.stream_;
-            data_.resize(o.data_.size());
+            data_.resize(o.data_.size(), stream_);
             if (o.data_.size())
             {
                 util::hip_check(moai_memcpy_d2d(data_.get(), o.data_.get(), o.data_.size() * 8, stream_));
@@ -834,7 +919,7 @@ namespace seal
             L_ = o.L_;
             scale_ = o.scale_;
             stream_ = o.stream_;
-            data_.resize(o.size_ * o.L_ * o.n_);
+            data_.resize(o.size_ * o.L_ * o.n_, stream_);
             if (data_.size())
             {
                 util::hip_check(moai_memcpy_d2d(data_.get(), o.data_.get(), data_.size() * 8, stream_));

@@ -46,6 +46,27 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint64_t *in, uint
 
 static const uint32_t NO_ZERO = 0xffffffffu;
 
+// out row y = sum over `splits` partial copies of in row (y * in_stride + in_off), mod the one prime
+__global__ __launch_bounds__(256) void sum_rows_kernel(const uint64_t *in, uint64_t *out, uint32_t in_stride, uint32_t in_off,
+                                                       uint32_t splits, size_t split_stride, const PrimeConst *pc,
+                                                       uint32_t prime, uint32_t n2)
+{
+    const uint64_t q = pc[prime].q;
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(in) + ((size_t)blockIdx.y * in_stride + in_off) * n2;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(out) + (size_t)blockIdx.y * n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 v = s[j];
+        for (uint32_t sp = 1; sp < splits; ++sp)
+        {
+            ulonglong2 y = s[j + sp * (split_stride >> 1)];
+            v.x = csub(v.x + y.x, q);
+            v.y = csub(v.y + y.y, q);
+        }
+        d[j] = v;
+    }
+}
+
 struct ExpandLastArgs
 {
     const uint64_t *last;  // [P][N], canonical under prime_last
@@ -243,7 +264,8 @@ static inline size_t align256(size_t x)
 //   acc row (p, i) = acc + (p * acc_stride + i) * N ; out [P][Lout][N]
 // scratch: u [P][Lout][N]
 static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32_t acc_stride, uint64_t *u,
-                   uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, bool accumulate, hipStream_t s)
+                   uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, bool accumulate, hipStream_t s,
+                   uint32_t acc_splits = 1, size_t acc_split_stride = 0)
 {
     RowMap rm;
     uint32_t pl = prime_last;
@@ -274,6 +296,8 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
         a.Lout = (uint32_t)Lout;
         a.P = (uint32_t)P;
         a.accumulate = accumulate ? 1 : 0;
+        a.acc_splits = acc_splits;
+        a.acc_split_stride = acc_split_stride;
         a.total_work = (uint32_t)(P * Lout * (c->n >> 12));
         bool noguard = true;
         for (size_t i = 0; i < Lout && noguard; ++i)
@@ -358,7 +382,7 @@ static int check_level(const moai_ctx *c, size_t L, size_t polys)
 
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, hipStream_t s);
+                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, hipStream_t s);
 
 // number of output moduli whose digits are in flight at once: bounded by the scratch budget
 // (MOAI_KS_TMP_MB, default 2048 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
@@ -388,6 +412,35 @@ static size_t ks_group_size(const moai_ctx *c, size_t L, size_t batch)
     return g;
 }
 
+// Few ciphertexts leave the MAC kernel with (L+1)*16*batch long-running workgroups, barely more than the
+// chip holds at two per CU, so its second round runs almost empty.  Splitting the digit range S ways gives
+// S times more, S times shorter workgroups; the partial sums are added where they are consumed.
+static uint32_t ks_splits(const moai_ctx *c, size_t L, size_t batch)
+{
+    if (c->logn < 12)
+    {
+        return 1;
+    }
+    const size_t wgs = batch * (L + 1) * (c->n >> 12);
+    const size_t want = (size_t)c->num_cu * 8;
+    size_t s = (want + wgs - 1) / wgs;
+    if (s > 8)
+    {
+        s = 8;
+    }
+    if (s > L)
+    {
+        s = L;
+    }
+    if (s < 1)
+    {
+        s = 1;
+    }
+    // no empty split: with chunks of ceil(L/s) digits, ceil(L/chunk) splits cover the range exactly
+    const size_t chunk = (L + s - 1) / s;
+    return (uint32_t)((L + chunk - 1) / chunk);
+}
+
 static size_t ks_tmp_rows(const moai_ctx *c, size_t L, size_t batch)
 {
     size_t fused = c->logn >= 12 ? batch * ks_group_size(c, L, batch) * L : 0;
@@ -399,7 +452,7 @@ static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
 {
     const size_t row_bytes = c->n * sizeof(uint64_t);
     return align256(batch * L * row_bytes) + align256(ks_tmp_rows(c, L, batch) * row_bytes) +
-           align256(batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
+           align256(ks_splits(c, L, batch) * batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
 }
 
 // which arithmetic discipline the primes of this context allow (keyswitch_kernels.cuh)
@@ -421,7 +474,7 @@ static int ks_mode(const moai_ctx *c, size_t L)
 
 template <int LOGN, int MODE>
 static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                               size_t batch, const KsGroup &grp, size_t G, hipStream_t s)
+                               size_t batch, const KsGroup &grp, size_t G, uint32_t splits, hipStream_t s)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     KsP1Args p1;
@@ -446,7 +499,10 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.G = (uint32_t)G;
     p2.k = (uint32_t)c->k;
     p2.B = (uint32_t)batch;
-    p2.total_work = (uint32_t)(batch * G * TPR);
+    p2.S = splits;
+    p2.jchunk = (uint32_t)((L + splits - 1) / splits);
+    p2.split_stride = batch * 2 * (L + 1) * c->n;
+    p2.total_work = (uint32_t)(batch * G * TPR * splits);
     hipLaunchKernelGGL((ks_contig_mac<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
@@ -454,13 +510,13 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
 
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, hipStream_t s)
+                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, hipStream_t s)
 {
     if (ks_mode(c, L))
     {
-        return ks_fused_group_mode<LOGN, 1>(c, t, tmp, key, acc, L, batch, grp, G, s);
+        return ks_fused_group_mode<LOGN, 1>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
     }
-    return ks_fused_group_mode<LOGN, 0>(c, t, tmp, key, acc, L, batch, grp, G, s);
+    return ks_fused_group_mode<LOGN, 0>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
 }
 
 // target row block of ciphertext b starts at target + (b * target_stride_rows + target_off_rows) * N.
@@ -482,7 +538,9 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     const size_t row_bytes = n * sizeof(uint64_t);
     const size_t sz_t = align256(batch * L * row_bytes);
     const size_t sz_ops = align256(ks_tmp_rows(c, L, batch) * row_bytes); // digits in flight; later u [2B][L][N]
-    const size_t sz_acc = align256(batch * 2 * (L + 1) * row_bytes);
+    const uint32_t splits = ks_splits(c, L, batch);
+    const size_t split_stride = batch * 2 * (L + 1) * n; // words
+    const size_t sz_acc = align256(splits * split_stride * sizeof(uint64_t));
     uint64_t *t = static_cast<uint64_t *>(wsp);
     uint64_t *ops = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_t);
     uint64_t *acc = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_t + sz_ops);
@@ -526,19 +584,19 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             switch (c->logn)
             {
             case 12:
-                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, s);
+                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
                 break;
             case 13:
-                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, s);
+                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
                 break;
             case 14:
-                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, s);
+                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
                 break;
             case 15:
-                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, s);
+                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
                 break;
             default:
-                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, s);
+                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
                 break;
             }
             if (rc)
@@ -579,10 +637,10 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         }
     }
     // 3. mod-down by the special prime, accumulated into ct   (evaluator.cpp:2913-3018)
-    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc, last, 1u, (uint32_t)(L + 1),
-                       (uint32_t)L, NO_ZERO, n2);
+    hipLaunchKernelGGL(sum_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc, last, (uint32_t)(L + 1), (uint32_t)L, splits,
+                       split_stride, c->pc, (uint32_t)(k - 1), n2);
     MOAI_LAUNCH_CHECK();
-    return moddown(c, last, acc, (uint32_t)(L + 1), ops, ct, batch * 2, L, (uint32_t)(k - 1), true, s);
+    return moddown(c, last, acc, (uint32_t)(L + 1), ops, ct, batch * 2, L, (uint32_t)(k - 1), true, s, splits, split_stride);
 }
 
 } // namespace moai

@@ -71,6 +71,9 @@ struct KsP2Args
     uint32_t G;
     uint32_t k;
     uint32_t B;          // ciphertexts in the batch
+    uint32_t S;          // digit range split: split s sums digits [s*jchunk, (s+1)*jchunk) into its own acc copy
+    uint32_t jchunk;
+    size_t split_stride; // words between the acc copies of consecutive splits
     uint32_t total_work;
 };
 
@@ -96,7 +99,11 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
     const uint32_t bq = w % a.B;
     w /= a.B;
     const uint32_t tile = w % TPR;
-    const uint32_t g = w / TPR;
+    w /= TPR;
+    const uint32_t g = w % a.G;
+    const uint32_t split = w / a.G;
+    const uint32_t j0 = split * a.jchunk;
+    const uint32_t j1 = (j0 + a.jchunk < a.L) ? j0 + a.jchunk : a.L;
     const uint32_t prime = a.grp.prime[g];
     const uint32_t slot = a.grp.slot[g];
     const PrimeConst *pc = a.pc + prime;
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {
-        x[j] = dig[(b << 8) | ((uint32_t)j << 4) | tl];
+        x[j] = dig[((size_t)j0 << LOGN) + ((b << 8) | ((uint32_t)j << 4) | tl)];
     }
-    for (uint32_t J = 0; J < a.L; ++J)
+    for (uint32_t J = j0; J < j1; ++J)
     {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
             }
             lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
         }
-        if (J + 1 < a.L)
+        if (J + 1 < j1)
         {
             const uint64_t *__restrict__ nxt = dig + ((size_t)(J + 1) << LOGN);
 #pragma unroll
@@ -220,9 +227,11 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
     }
     const uint64_t cr0 = pc->cr0, cr1 = pc->cr1;
     ulonglong2 *__restrict__ o0 =
-        reinterpret_cast<ulonglong2 *>(a.acc + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN)) + ((size_t)tile << 11);
+        reinterpret_cast<ulonglong2 *>(a.acc + split * a.split_stride + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN)) +
+        ((size_t)tile << 11);
     ulonglong2 *__restrict__ o1 =
-        reinterpret_cast<ulonglong2 *>(a.acc + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN)) + ((size_t)tile << 11);
+        reinterpret_cast<ulonglong2 *>(a.acc + split * a.split_stride + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN)) +
+        ((size_t)tile << 11);
 #pragma unroll
     for (int it = 0; it < 8; ++it)
     {
@@ -253,14 +262,22 @@ struct LoadExpandLast
 
 struct StoreModDown
 {
-    const ulonglong2 *acc; // tile base of the row being divided
+    const ulonglong2 *acc; // tile base of the row being divided (first of `splits` partial copies)
     ulonglong2 *out;       // tile base of the result row
     uint64_t q;
     Tw inv;
     int accumulate;
+    uint32_t splits;       // partial sums to add up (key switch on few ciphertexts), 1 otherwise
+    size_t split_stride;   // 16-byte chunks between consecutive partial copies
     __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 u) const
     {
         ulonglong2 x = acc[ch], r;
+        for (uint32_t sp = 1; sp < splits; ++sp)
+        {
+            ulonglong2 y = acc[ch + sp * split_stride];
+            x.x = csub(x.x + y.x, q);
+            x.y = csub(x.y + y.y, q);
+        }
         r.x = csub(mul_shoup_lazy(x.x + q - u.x, inv.w, inv.wq, q), q);
         r.y = csub(mul_shoup_lazy(x.y + q - u.y, inv.w, inv.wq, q), q);
         if (accumulate)
@@ -288,6 +305,8 @@ struct ModDownArgs
     uint32_t Lout;
     uint32_t P;
     int accumulate;
+    uint32_t acc_splits;     // >= 1
+    size_t acc_split_stride; // words between partial copies of acc
     uint32_t total_work;
 };
 
@@ -331,6 +350,8 @@ __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
     st.q = pc->q;
     st.inv = a.inv_last[i];
     st.accumulate = a.accumulate;
+    st.splits = a.acc_splits;
+    st.split_stride = a.acc_split_stride >> 1;
     fwd_contig_tile<LOGN, NOGUARD, StoreModDown>(a.u + (((size_t)p * a.Lout + i) << LOGN), tile, a.tw + ((size_t)i << LOGN), pc->q,
                                                  pc->q2, lds2, threadIdx.x, a.twb + (size_t)i * ((size_t)TPR * 15 * 256),
                                                  pc->cr1, st);

@@ -502,8 +502,8 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.S = splits;
     p2.jchunk = (uint32_t)((L + splits - 1) / splits);
     p2.split_stride = batch * 2 * (L + 1) * c->n;
-    p2.total_work = (uint32_t)(batch * G * TPR * splits);
-    hipLaunchKernelGGL((ks_contig_mac<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
+    p2.total_work = (uint32_t)(batch * G * TPR * 2 * splits); // 2048-coefficient tiles
+    hipLaunchKernelGGL((ks_contig_mac8<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
 }
@@ -567,7 +567,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     {
         // fused: "mod q_I" rides on the strided pass's loads, the key MAC on the contiguous pass
         const size_t G = ks_group_size(c, L, batch);
-        if (batch * G * L * (n >> 12) > 0x7fffffffull)
+        if (batch * G * L * (n >> 11) > 0x7fffffffull)
         {
             return set_error(MOAI_EINVAL, "batch too large for one launch");
         }

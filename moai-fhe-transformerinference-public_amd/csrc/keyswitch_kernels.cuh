@@ -6,7 +6,7 @@
 // the contiguous pass never writes the transformed digit back: one workgroup owns a 4096-coefficient
 // tile of the output (modulus I, ciphertext b), loops over the L digits, finishes each digit's last 8
 // stages in registers and multiplies it straight into 128-bit accumulators for both key components
-// (ks_contig_mac).  Per (I, J) coefficient this moves 8 B (read t) + 16 B (intermediate) + 16 B (key,
+// (ks_contig_mac8).  Per (I, J) coefficient this moves 8 B (read t) + 16 B (intermediate) + 16 B (key,
 // shared by the batch through L2) instead of 56 B + key for the unfused sequence
 // reduce -> NTT -> NTT -> MAC.
 #pragma once
@@ -85,21 +85,42 @@ __device__ __forceinline__ void mac128r(uint64_t &lo, uint64_t &hi, uint64_t a, 
     hi += ph + (lo < pl ? 1 : 0);
 }
 
+// ---- contiguous pass + key MAC, 8 coefficients per thread --------------------------------------------------------
+// With the NTT kernels' 16 coefficients per thread the 2 x 16 128-bit accumulators need 250 VGPRs (two waves
+// per SIMD; measured 6-12 % slower).  Here a workgroup owns a 2048-coefficient tile (8 blocks of 256): radix-8 /
+// radix-8 / radix-4 with two LDS exchanges, and the MAC runs straight from the registers that finish the
+// transform; 128 VGPRs, four waves per SIMD.
+// layouts of the 8 registers of thread (b = tid >> 5, r = tid & 31), t = coefficient index inside block b:
+//   P1  t = (j << 5) | r                         stages 0..2 (t bits 7..5)
+//   P2  t = (r >> 2) << 5 | j << 2 | (r & 3)      stages 3..5 (t bits 4..2)
+//   P3  t = r << 3 | j                            stages 6..7 (t bits 1..0); 8 contiguous coefficients
+// LDS swizzles keep every exchange conflict free: exchange 1 stores t with bits 4..2 ^= bits 7..5, exchange 2
+// stores t with bits 2..1 ^= bits 6..5.
+__device__ __forceinline__ uint32_t phys8_a(uint32_t e)
+{
+    return e ^ (((e >> 5) & 7u) << 2);
+}
+
+__device__ __forceinline__ uint32_t phys8_b(uint32_t e)
+{
+    return e ^ (((e >> 5) & 3u) << 1);
+}
+
 template <int LOGN, int MODE>
-__global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
+__global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
 {
     constexpr int R1 = LOGN - 8;
-    constexpr uint32_t TPR = 1u << (LOGN - 12);
-    __shared__ ulonglong2 lds2[2048];
-    uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
+    constexpr uint32_t TPR8 = 1u << (LOGN - 11);
+    __shared__ ulonglong2 lds_a2[1024];
+    __shared__ ulonglong2 lds_b2[1024];
+    uint64_t *lds_a = reinterpret_cast<uint64_t *>(lds_a2);
+    uint64_t *lds_b = reinterpret_cast<uint64_t *>(lds_b2);
 
-    // ciphertext index fastest: the workgroups that run side by side on one XCD walk the same key tiles
-    // (modulus I, tile, J = 0..L-1), so each key line is fetched from HBM once per XCD, not once per ciphertext
     uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t bq = w % a.B;
     w /= a.B;
-    const uint32_t tile = w % TPR;
-    w /= TPR;
+    const uint32_t tile = w % TPR8;
+    w /= TPR8;
     const uint32_t g = w % a.G;
     const uint32_t split = w / a.G;
     const uint32_t j0 = split * a.jchunk;
@@ -109,140 +130,145 @@ __global__ __launch_bounds__(256, 2) void ks_contig_mac(KsP2Args a)
     const PrimeConst *pc = a.pc + prime;
     const uint64_t q = pc->q, q2 = pc->q2;
     const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t b = tid >> 4;
-    const uint32_t tl = tid & 15u;
-    const uint32_t blk = (tile << 4) + b;
-    const uint32_t myrow = tid;
+    const uint32_t tid0 = threadIdx.x;
 
-    uint64_t lo0[16], hi0[16], lo1[16], hi1[16];
+    uint64_t lo0[8], hi0[8], lo1[8], hi1[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int e = 0; e < 8; ++e)
     {
         lo0[e] = hi0[e] = lo1[e] = hi1[e] = 0;
     }
+    const uint64_t *__restrict__ dig = a.tmp + ((((size_t)bq * a.G + g) * a.L) << LOGN) + ((size_t)tile << 11);
 
-    // software pipeline: digit J+1 is loaded into the (then dead) coefficient registers while digit J is
-    // being multiplied into the accumulators
-    const uint64_t *__restrict__ dig = a.tmp + ((((size_t)bq * a.G + g) * a.L) << LOGN) + ((size_t)tile << 12);
-    uint64_t x[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-    {
-        x[j] = dig[((size_t)j0 << LOGN) + ((b << 8) | ((uint32_t)j << 4) | tl)];
-    }
     for (uint32_t J = j0; J < j1; ++J)
     {
+        // opaque copy of the thread index: keeps the per-thread address arithmetic inside the loop instead of
+        // hoisted into (and spilled from) registers the accumulators need
+        uint32_t tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const uint32_t b = tid >> 5;
+        const uint32_t r = tid & 31u;
+        const uint32_t hi3 = r >> 2, lo2 = r & 3u;
+        const uint32_t blk = (tile << 3) + b;
+        // chunk (16 bytes = 2 coefficients) of this thread's 8 contiguous coefficients inside the tile
+        const uint32_t ch0 = (b << 7) | (r << 2);
+        const uint64_t *__restrict__ base = dig + ((size_t)J << LOGN);
+        uint64_t x[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int j = 0; j < 8; ++j)
         {
-            const int half = 8 >> u;
+            x[j] = base[(b << 8) | ((uint32_t)j << 5) | r];
+        }
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+        for (int u = 0; u < 3; ++u)
+        {
+            const int half = 4 >> u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
             {
                 if (!(j & half))
                 {
-                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
+                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))];
                     ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < 8; ++j)
         {
-            lds[phys_contig((b << 8) | ((uint32_t)j << 4) | tl)] = x[j];
+            lds_a[phys8_a((b << 8) | ((uint32_t)j << 5) | r)] = x[j];
         }
         lds_barrier();
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int j = 0; j < 8; ++j)
         {
-            ulonglong2 v = lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))];
-            x[2 * c] = v.x;
-            x[2 * c + 1] = v.y;
+            x[j] = lds_a[phys8_a((b << 8) | (hi3 << 5) | ((uint32_t)j << 2) | lo2)];
         }
 #pragma unroll
-        for (int u = 4; u < 8; ++u)
+        for (int u = 3; u < 6; ++u)
         {
-            const int half = 8 >> (u - 4);
+            const int half = 4 >> (u - 3);
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+            for (int j = 0; j < 8; ++j)
             {
                 if (!(j & half))
                 {
-                    // the plain table here: the same 15 entries per thread are re-read for every digit J, and a
-                    // thread's 8 last-stage entries share one 128-byte line (measured faster than the
-                    // per-thread-ordered copy the NTT kernels use)
-                    uint32_t t_ = (tl << 4) | (uint32_t)j;
+                    uint32_t t_ = (hi3 << 5) | ((uint32_t)j << 2) | lo2;
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
                     ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
-        // rows are private to their thread: write the canonical values back into the same slots
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int j = 0; j < 8; ++j)
         {
-            ulonglong2 v;
-            if (MODE == 0)
-            {
-                v.x = csub(csub(x[2 * c], q2), q);
-                v.y = csub(csub(x[2 * c + 1], q2), q);
-            }
-            else
-            {
-                v.x = x[2 * c];
-                v.y = x[2 * c + 1];
-            }
-            lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
-        }
-        if (J + 1 < j1)
-        {
-            const uint64_t *__restrict__ nxt = dig + ((size_t)(J + 1) << LOGN);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-            {
-                x[j] = nxt[(b << 8) | ((uint32_t)j << 4) | tl];
-            }
+            lds_b[phys8_b((b << 8) | (hi3 << 5) | ((uint32_t)j << 2) | lo2)] = x[j];
         }
         lds_barrier();
-        // coalesced view of the tile: chunk ch = it * 256 + tid; multiply into both key components
-        const ulonglong2 *__restrict__ k0 =
-            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 11);
-        const ulonglong2 *__restrict__ k1 =
-            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN)) + ((size_t)tile << 11);
 #pragma unroll
-        for (int it = 0; it < 8; ++it)
+        for (int c = 0; c < 4; ++c)
         {
-            uint32_t ch = (uint32_t)it * 256u + tid;
-            uint32_t rr = ch >> 3;
-            ulonglong2 v = lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))];
-            ulonglong2 ka = k0[ch];
-            ulonglong2 kb = k1[ch];
-            mac128r(lo0[2 * it], hi0[2 * it], v.x, ka.x);
-            mac128r(lo0[2 * it + 1], hi0[2 * it + 1], v.y, ka.y);
-            mac128r(lo1[2 * it], hi1[2 * it], v.x, kb.x);
-            mac128r(lo1[2 * it + 1], hi1[2 * it + 1], v.y, kb.y);
+            // coefficients (r << 3) | 2c, 2c+1: chunk c of the row, stored at chunk c ^ ((r >> 2) & 3)
+            ulonglong2 v = lds_b2[((b << 8) | (r << 3)) / 2 + ((uint32_t)c ^ ((r >> 2) & 3u))];
+            x[2 * c] = v.x;
+            x[2 * c + 1] = v.y;
         }
-        lds_barrier(); // the tile is dead: the next digit may overwrite it
+#pragma unroll
+        for (int u = 6; u < 8; ++u)
+        {
+            const int half = 2 >> (u - 6);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                if (!(j & half))
+                {
+                    uint32_t t_ = (r << 3) | (uint32_t)j;
+                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
+                    ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
+                }
+            }
+        }
+        const ulonglong2 *__restrict__ k0 =
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
+        const ulonglong2 *__restrict__ k1 =
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            uint64_t vx = x[2 * c], vy = x[2 * c + 1];
+            if (MODE == 0)
+            {
+                vx = csub(csub(vx, q2), q);
+                vy = csub(csub(vy, q2), q);
+            }
+            ulonglong2 ka = k0[c];
+            ulonglong2 kb = k1[c];
+            mac128r(lo0[2 * c], hi0[2 * c], vx, ka.x);
+            mac128r(lo0[2 * c + 1], hi0[2 * c + 1], vy, ka.y);
+            mac128r(lo1[2 * c], hi1[2 * c], vx, kb.x);
+            mac128r(lo1[2 * c + 1], hi1[2 * c + 1], vy, kb.y);
+        }
+        // no barrier here: the next digit writes buffer A, whose readers all passed the second barrier above,
+        // and buffer B is written again only after the next first barrier
     }
+    const uint32_t ch0 = ((tid0 >> 5) << 7) | ((tid0 & 31u) << 2);
     const uint64_t cr0 = pc->cr0, cr1 = pc->cr1;
     ulonglong2 *__restrict__ o0 =
         reinterpret_cast<ulonglong2 *>(a.acc + split * a.split_stride + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN)) +
-        ((size_t)tile << 11);
+        ((size_t)tile << 10) + ch0;
     ulonglong2 *__restrict__ o1 =
         reinterpret_cast<ulonglong2 *>(a.acc + split * a.split_stride + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN)) +
-        ((size_t)tile << 11);
+        ((size_t)tile << 10) + ch0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
+    for (int c = 0; c < 4; ++c)
     {
-        uint32_t ch = (uint32_t)it * 256u + tid;
         ulonglong2 r0, r1;
-        r0.x = barrett128(lo0[2 * it], hi0[2 * it], q, cr0, cr1);
-        r0.y = barrett128(lo0[2 * it + 1], hi0[2 * it + 1], q, cr0, cr1);
-        r1.x = barrett128(lo1[2 * it], hi1[2 * it], q, cr0, cr1);
-        r1.y = barrett128(lo1[2 * it + 1], hi1[2 * it + 1], q, cr0, cr1);
-        o0[ch] = r0;
-        o1[ch] = r1;
+        r0.x = barrett128(lo0[2 * c], hi0[2 * c], q, cr0, cr1);
+        r0.y = barrett128(lo0[2 * c + 1], hi0[2 * c + 1], q, cr0, cr1);
+        r1.x = barrett128(lo1[2 * c], hi1[2 * c], q, cr0, cr1);
+        r1.y = barrett128(lo1[2 * c + 1], hi1[2 * c + 1], q, cr0, cr1);
+        o0[c] = r0;
+        o1[c] = r1;
     }
 }
 

@@ -50,13 +50,23 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
     const uint32_t b = w / a.L;
     const uint32_t prime = a.grp.prime[g];
     const PrimeConst *pc = a.pc + prime;
-    LoadBarrett op;
-    op.q = pc->q;
-    op.cr1 = pc->cr1;
     const uint64_t *in = a.t + (((size_t)b * a.L + J) << LOGN);
     uint64_t *out = a.tmp + ((((size_t)b * a.G + g) * a.L + J) << LOGN);
-    fwd_strided_tile<LOGN, LoadBarrett, (MODE != 0)>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds,
-                                                     threadIdx.x, op);
+    // digit J is canonical under prime J: it needs reducing only when that prime is the larger one
+    // (SEAL/evaluator.cpp:2846-2854); the branch is workgroup-uniform
+    if (a.pc[J].q > pc->q)
+    {
+        LoadBarrett op;
+        op.q = pc->q;
+        op.cr1 = pc->cr1;
+        fwd_strided_tile<LOGN, LoadBarrett, (MODE != 0)>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds,
+                                                         threadIdx.x, op);
+    }
+    else
+    {
+        fwd_strided_tile<LOGN, LoadIdentity, (MODE != 0)>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds,
+                                                          threadIdx.x);
+    }
 }
 
 struct KsP2Args

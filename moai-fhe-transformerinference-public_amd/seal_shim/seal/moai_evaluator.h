@@ -54,6 +54,18 @@ namespace seal
             {
                 add_inplace(destination, encrypted1);
             }
+            else if (&encrypted1 == &destination)
+            {
+                add_inplace(destination, encrypted2);
+            }
+            else if (encrypted1.size() == encrypted2.size() && encrypted1.size() >= 2)
+            {
+                // equal sizes: one kernel straight into the destination, no deep copy first
+                check_pair(encrypted1, encrypted2);
+                like(destination, encrypted1);
+                hip(moai_add(dev(), encrypted1.device_data(), encrypted2.device_data(), destination.device_data(),
+                             encrypted1.size(), encrypted1.coeff_modulus_size(), st()));
+            }
             else
             {
                 destination = encrypted1;
@@ -89,6 +101,17 @@ namespace seal
             {
                 sub_inplace(destination, encrypted1);
                 negate_inplace(destination);
+            }
+            else if (&encrypted1 == &destination)
+            {
+                sub_inplace(destination, encrypted2);
+            }
+            else if (encrypted1.size() == encrypted2.size() && encrypted1.size() >= 2)
+            {
+                check_pair(encrypted1, encrypted2);
+                like(destination, encrypted1);
+                hip(moai_sub(dev(), encrypted1.device_data(), encrypted2.device_data(), destination.device_data(),
+                             encrypted1.size(), encrypted1.coeff_modulus_size(), st()));
             }
             else
             {
@@ -629,8 +652,8 @@ namespace seal
             }
         }
 
-        // SEAL/evaluator.cpp:155-240 / :263-350
-        void addsub(Ciphertext &e1, const Ciphertext &e2, bool sub) const
+        // the argument checks of add / sub, SEAL/evaluator.cpp:157-180
+        void check_pair(const Ciphertext &e1, const Ciphertext &e2) const
         {
             check_ct(e1, "encrypted1");
             check_ct(e2, "encrypted2");
@@ -646,6 +669,12 @@ namespace seal
             {
                 throw std::invalid_argument("scale mismatch");
             }
+        }
+
+        // SEAL/evaluator.cpp:155-240 / :263-350
+        void addsub(Ciphertext &e1, const Ciphertext &e2, bool sub) const
+        {
+            check_pair(e1, e2);
             const std::size_t L = e1.coeff_modulus_size(), n = e1.poly_modulus_degree();
             const std::size_t min_size = std::min(e1.size(), e2.size());
             const std::size_t max_size = std::max(e1.size(), e2.size());

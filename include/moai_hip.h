@@ -190,6 +190,31 @@ int moai_apply_galois(moai_ctx *ctx, uint64_t *ct, size_t L, uint32_t galois_elt
  * in: [batch][2][1][N] (NTT form under prime 0) -> out: [batch][2][L_out][N] (NTT form). */
 int moai_modraise(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream);
 
+/* ---- CKKS encoder ---------------------------------------------------------
+ * CKKSEncoder::encode_internal, vector form, SEAL/ckks.h:457-637, for n_batch value vectors in one call:
+ * scatter into the conjugate-symmetric slot vector (matrix_reps_index_map_, ckks.cpp:34-52, generator 5),
+ * FP64 inverse DWT with scale / N folded into the last stage (util/dwthandler.h:202-356 on
+ * std::complex<double>, every product and sum rounded separately as the reference's x86-64 build does),
+ * std::round, exact residues of the rounded integers, forward NTT.
+ *   values     device, [n_batch][values_size] doubles (is_complex = 0) or (re, im) pairs (is_complex = 1);
+ *              values_size <= N/2, shorter vectors are zero-padded like the reference
+ *   dst        device, [n_batch][L][N], rows over context primes prime_index[0..L) (NULL = 0..L-1), NTT form
+ *   max_coeff  device, [n_batch] doubles, or NULL: max |coefficient| before rounding, i.e. the quantity
+ *              ckks.h:527-538 turns into max_coeff_bit_count; the caller compares it with
+ *              moai_total_coeff_modulus_bit_count to raise "encoded values are too large"
+ * The three decomposition branches of the reference (<= 64 bits, <= 128 bits, multi-word) all produce the
+ * exact integer modulo each prime; so does the single device routine.
+ * Errors: MOAI_EINVAL "values_size is too large" / "scale out of bounds" (ckks.h:469-497). */
+int moai_ckks_encode(moai_ctx *ctx, const double *values, int is_complex, size_t values_size, size_t n_batch,
+                     uint64_t *dst, size_t L, const uint32_t *prime_index, double scale, double *max_coeff,
+                     void *stream);
+/* ContextData::total_coeff_modulus_bit_count (SEAL/context.cpp:169-173): significant bits of the product of
+ * the L primes; 0 on error. */
+int moai_total_coeff_modulus_bit_count(const moai_ctx *ctx, size_t L, const uint32_t *prime_index);
+/* The tables the encoder uses, for inspection by tests: matrix_reps_index_map_ (host copy, N entries) and
+ * inv_root_powers_ (host copy, N (re, im) pairs; ckks.cpp:54-71 via util/croots.cpp). */
+int moai_ckks_tables(moai_ctx *ctx, uint32_t *index_map, double *inv_root_powers);
+
 /* ---- measurement support -----------------------------------------------------------------------------------
  * Average duration in milliseconds of the NTT kernels of the last moai_ntt_* call recorded with
  * HIP events on the caller's stream is not provided here; callers time with their own events

@@ -86,6 +86,11 @@ struct moai_ctx
     std::map<void *, Arena> ws;
     // Galois permutation tables, built lazily per element (galois.cpp:18-51)
     std::vector<uint32_t *> galois_tables; // [N] entries index (elt-1)>>1, device pointers
+    // CKKSEncoder tables (SEAL/ckks.cpp:13-76), built on the first moai_ckks_encode
+    std::vector<uint32_t> ckks_index_map;     // matrix_reps_index_map_ [N]
+    std::vector<double> ckks_inv_roots_host;  // inv_root_powers_ [N] (re, im)
+    uint32_t *ckks_src_map = nullptr;         // device, inverse of ckks_index_map
+    double *ckks_inv_roots = nullptr;         // device copy
     void *mutex = nullptr;
     // serialises the enqueue of multi-kernel operations that share a stream's workspace arena: callers
     // on different host threads may target the same stream (MOAI's OpenMP loops do)

@@ -382,6 +382,8 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
             (void)hipFree(t);
         }
     }
+    (void)hipFree(c->ckks_src_map);
+    (void)hipFree(c->ckks_inv_roots);
     delete static_cast<std::mutex *>(c->mutex);
     delete static_cast<std::mutex *>(c->op_mutex);
     delete c;

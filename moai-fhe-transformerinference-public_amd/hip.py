@@ -56,12 +56,18 @@ SYMBOLS = {
     "moai_relinearize": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_apply_galois": (C.c_int, [vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_modraise": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_ckks_encode": (C.c_int, [vp, vp, C.c_int, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
+    "moai_total_coeff_modulus_bit_count": (C.c_int, [vp, sz, C.POINTER(C.c_uint32)]),
+    "moai_ckks_tables": (C.c_int, [vp, vp, vp]),
     "moai_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
     "moai_event_create": (C.c_int, [C.POINTER(vp)]),
     "moai_event_destroy": (C.c_int, [vp]),
     "moai_event_record": (C.c_int, [vp, vp]),
     "moai_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
 }
+
+
+MOAI_EINVAL = -1  # include/moai_hip.h
 
 
 class MoaiError(RuntimeError):
@@ -250,6 +256,45 @@ class Context:
 
     def modraise(self, src, out, L_out, batch, stream=None):
         _check(lib().moai_modraise(self.h, _ptr(src), _ptr(out), L_out, batch, stream))
+
+    def ckks_encode(self, values, L, scale, prime_index=None, stream=None):
+        """CKKSEncoder::encode for a batch of vectors: values [n_batch][count] float64 or complex128 (host).
+        Returns (DeviceBuffer [n_batch][L][N] in NTT form, max |coefficient| per vector); raises like
+        the reference when a vector does not fit the level's modulus (SEAL/ckks.h:527-538)."""
+        v = np.asarray(values)
+        is_complex = np.iscomplexobj(v)
+        v = np.ascontiguousarray(v, dtype=np.complex128 if is_complex else np.float64)
+        if v.ndim == 1:
+            v = v[None, :]
+        n_batch, count = v.shape
+        words = v.size * (2 if is_complex else 1)
+        dv = DeviceBuffer(max(words, 1) + n_batch)
+        _check(lib().moai_memcpy_h2d(dv.ptr, v.ctypes.data, words * 8, stream))
+        out = DeviceBuffer(n_batch * L * self.n)
+        mx_ptr = dv.ptr + max(words, 1) * 8
+        _check(lib().moai_ckks_encode(self.h, dv.ptr, 1 if is_complex else 0, count, n_batch, out.ptr, L,
+                                      self._pidx(prime_index), float(scale), mx_ptr, stream))
+        mx = np.empty(n_batch, dtype=np.float64)
+        _check(lib().moai_stream_sync(stream))
+        _check(lib().moai_memcpy_d2h(mx.ctypes.data, mx_ptr, n_batch * 8, stream))
+        _check(lib().moai_stream_sync(stream))
+        total = self.total_coeff_modulus_bit_count(L, prime_index)
+        bits = np.ceil(np.log2(np.maximum(mx, 1.0))).astype(int) + 1
+        if np.any(bits >= total) or not np.all(np.isfinite(mx)):
+            raise MoaiError(MOAI_EINVAL, "encoded values are too large")
+        return out, mx
+
+    def total_coeff_modulus_bit_count(self, L, prime_index=None):
+        r = lib().moai_total_coeff_modulus_bit_count(self.h, L, self._pidx(prime_index))
+        if r == 0:
+            _check(MOAI_EINVAL)
+        return r
+
+    def ckks_tables(self):
+        idx = np.empty(self.n, dtype=np.uint32)
+        roots = np.empty((self.n, 2), dtype=np.float64)
+        _check(lib().moai_ckks_tables(self.h, idx.ctypes.data, roots.ctypes.data))
+        return idx, roots
 
     def sync(self, stream=None):
         _check(lib().moai_stream_sync(stream))

@@ -271,30 +271,16 @@ namespace seal
             }
         }
 
-        // inverse DWT, bit-reversed in -> natural out (transform_from_rev), unscaled
-        void fft_from_rev(std::vector<std::complex<double>> &v) const
+        static const double *as_doubles(const double *v)
         {
-            const std::size_t n = v.size();
-            std::size_t gap = 1, m = n >> 1;
-            for (; m >= 1; m >>= 1)
-            {
-                std::size_t offset = 0;
-                for (std::size_t i = 0; i < m; i++)
-                {
-                    const std::complex<double> r = inv_root_powers_[m + i];
-                    for (std::size_t j = 0; j < gap; j++)
-                    {
-                        std::complex<double> u = v[offset + j];
-                        std::complex<double> t = v[offset + gap + j];
-                        v[offset + j] = u + t;
-                        v[offset + gap + j] = (u - t) * r;
-                    }
-                    offset += gap << 1;
-                }
-                gap <<= 1;
-            }
+            return v;
+        }
+        static const double *as_doubles(const std::complex<double> *v)
+        {
+            return reinterpret_cast<const double *>(v); // (re, im) pairs, [complex.numbers.general]
         }
 
+        // SEAL/ckks.h:457-637 on the device (moai_ckks_encode): only the values go over PCIe
         template <typename T>
         void encode_vector(const T *values, std::size_t count, parms_id_type parms_id, double scale,
                            Plaintext &destination) const
@@ -303,6 +289,10 @@ namespace seal
             if (!cd)
             {
                 throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            }
+            if (!values && count > 0)
+            {
+                throw std::invalid_argument("values cannot be null");
             }
             if (count > slots_)
             {
@@ -313,54 +303,38 @@ namespace seal
             {
                 throw std::invalid_argument("scale out of bounds");
             }
+            const bool is_complex = std::is_same<T, std::complex<double>>::value;
             const std::size_t n = context_.n();
-            std::vector<std::complex<double>> conj_values(n, std::complex<double>(0.0, 0.0));
-            for (std::size_t i = 0; i < count; i++)
-            {
-                std::complex<double> c = as_complex(values[i]);
-                conj_values[index_map_[i]] = c;
-                conj_values[index_map_[slots_ + i]] = std::conj(c);
-            }
-            fft_from_rev(conj_values);
-            const double fix = scale / static_cast<double>(n);
             const std::size_t L = cm.size();
-            std::vector<std::uint64_t> rns(L * n);
-            for (std::size_t i = 0; i < n; i++)
+            const std::size_t words = count * (is_complex ? 2 : 1);
+            void *stream = context_.stream();
+            util::DeviceArray staging(words + 1, stream); // values, then max |coefficient|
+            if (words)
             {
-                double c = std::round(conj_values[i].real() * fix);
-                if (!(std::fabs(c) < 1.7e38))
-                {
-                    throw std::invalid_argument("encoded values are too large");
-                }
-                bool neg = c < 0;
-                double a = std::fabs(c);
-                // |c| as an exact 128-bit integer
-                int e;
-                double mant = std::frexp(a, &e); // a = mant * 2^e, mant in [0.5,1)
-                util::u128 mag = 0;
-                if (a != 0.0)
-                {
-                    std::uint64_t m53 = static_cast<std::uint64_t>(std::ldexp(mant, 53));
-                    int sh = e - 53;
-                    mag = sh >= 0 ? (static_cast<util::u128>(m53) << sh) : (static_cast<util::u128>(m53) >> (-sh));
-                }
-                for (std::size_t r = 0; r < L; r++)
-                {
-                    const std::uint64_t q = cm[r].value();
-                    std::uint64_t v = static_cast<std::uint64_t>(mag % q);
-                    rns[r * n + i] = (neg && v) ? q - v : v;
-                }
+                util::hip_check(moai_memcpy_h2d(staging.get(), as_doubles(values), words * 8, stream));
             }
             destination.scalar_rows_.clear();
-            destination.parms_id_ = parms_id;
-            destination.scale_ = scale;
+            destination.parms_id_ = parms_id_zero;
             destination.n_ = n;
             destination.L_ = L;
-            destination.stream_ = context_.stream();
-            destination.data_.resize(L * n, context_.stream());
-            util::hip_check(moai_memcpy_h2d(destination.data_.get(), rns.data(), L * n * 8, context_.stream()));
-            context_.sync(); // rns is a stack-owned buffer
-            util::hip_check(moai_ntt_forward(context_.device(), destination.data_.get(), 1, L, nullptr, context_.stream()));
+            destination.stream_ = stream;
+            destination.data_.resize(L * n, stream);
+            double *max_dev = reinterpret_cast<double *>(staging.get() + words);
+            util::hip_check(moai_ckks_encode(context_.device(), reinterpret_cast<const double *>(staging.get()),
+                                             is_complex ? 1 : 0, count, 1, destination.data_.get(), L, nullptr, scale,
+                                             max_dev, stream));
+            double max_coeff = 0;
+            util::hip_check(moai_memcpy_d2h(&max_coeff, max_dev, 8, stream));
+            context_.sync();
+            // ckks.h:527-538 (the negated comparison also catches NaN)
+            int max_coeff_bit_count = static_cast<int>(std::ceil(std::log2(std::max<>(max_coeff, 1.0)))) + 1;
+            if (!(max_coeff_bit_count < cd->total_coeff_modulus_bit_count()))
+            {
+                destination.data_.release();
+                throw std::invalid_argument("encoded values are too large");
+            }
+            destination.parms_id_ = parms_id;
+            destination.scale_ = scale;
         }
 
         void encode_scalar(double value, parms_id_type parms_id, double scale, Plaintext &destination) const
@@ -371,33 +345,46 @@ namespace seal
                 throw std::invalid_argument("parms_id is not valid for encryption parameters");
             }
             const auto &cm = cd->parms().coeff_modulus();
-            if (scale <= 0 || (static_cast<int>(std::log2(scale)) + 1 >= cd->total_coeff_modulus_bit_count()))
+            // SEAL/ckks.cpp:101-115
+            if (scale <= 0 || (static_cast<int>(std::log2(scale)) >= cd->total_coeff_modulus_bit_count()))
             {
                 throw std::invalid_argument("scale out of bounds");
             }
-            // SEAL/ckks.cpp:101-150: round(value * scale), one residue per prime, every coefficient of
-            // the NTT-form row equal to it
-            double c = std::round(value * scale);
-            if (!(std::fabs(c) < 1.7e38))
+            value *= scale;
+            int coeff_bit_count = value == 0.0 ? 1 : static_cast<int>(std::log2(std::fabs(value))) + 2;
+            if (coeff_bit_count >= cd->total_coeff_modulus_bit_count())
             {
                 throw std::invalid_argument("encoded value is too large");
             }
-            bool neg = c < 0;
+            // ckks.cpp:126-211: round, then the exact integer modulo each prime (all three branches of the
+            // reference compute that), sign applied by negate_uint_mod; every coefficient of the NTT-form
+            // row equals it, so only the L residues are kept
+            double c = std::round(value);
+            bool neg = std::signbit(c);
             double a = std::fabs(c);
-            int e;
-            double mant = std::frexp(a, &e);
-            util::u128 mag = 0;
-            if (a != 0.0)
-            {
-                std::uint64_t m53 = static_cast<std::uint64_t>(std::ldexp(mant, 53));
-                int sh = e - 53;
-                mag = sh >= 0 ? (static_cast<util::u128>(m53) << sh) : (static_cast<util::u128>(m53) >> (-sh));
-            }
+            int e = 0;
+            double mant = std::frexp(a, &e); // a = mant * 2^e, mant in [0.5, 1)
+            std::uint64_t m53 = a != 0.0 ? static_cast<std::uint64_t>(std::ldexp(mant, 53)) : 0;
+            int sh = e - 53;
             destination.scalar_rows_.resize(cm.size());
             for (std::size_t r = 0; r < cm.size(); r++)
             {
                 const std::uint64_t q = cm[r].value();
-                std::uint64_t v = static_cast<std::uint64_t>(mag % q);
+                std::uint64_t v;
+                if (sh <= 0)
+                {
+                    v = (sh > -64 ? (m53 >> (-sh)) : 0) % q;
+                }
+                else
+                {
+                    v = m53 % q;
+                    for (int left = sh; left > 0;)
+                    {
+                        int step = left < 63 ? left : 63;
+                        v = static_cast<std::uint64_t>((static_cast<util::u128>(v) << step) % q);
+                        left -= step;
+                    }
+                }
                 destination.scalar_rows_[r] = (neg && v) ? q - v : v;
             }
             destination.parms_id_ = parms_id;

@@ -9,6 +9,7 @@
  * (radix-2 Harvey butterflies with Shoup twiddles, base-2^64 Barrett, per-prime key-switch digits
  * with one special prime) so that the CPU baseline is not a strawman.
  */
+#define _GNU_SOURCE /* sincos */
 #include "moai_oracle.h"
 
 #include <stdlib.h>
@@ -1245,4 +1246,344 @@ void mo_modraise(const mo_context *c, const uint64_t *in, size_t Lout, uint64_t 
         }
     }
     free(src);
+}
+
+/* ==== SEAL/ckks.{h,cpp}: CKKSEncoder ========================================================= */
+#include <math.h>
+
+void mo_complex_get_root(size_t degree, const double *roots8, size_t index, double out[2])
+{
+    /* SEAL/util/croots.cpp:44-75: 8-fold symmetry of the degree-th roots of unity */
+    double t[2];
+    index &= degree - 1;
+    if (index <= degree / 8)
+    {
+        out[0] = roots8[2 * index];
+        out[1] = roots8[2 * index + 1];
+    }
+    else if (index <= degree / 4)
+    {
+        /* mirror(a) = (imag, real) */
+        out[0] = roots8[2 * (degree / 4 - index) + 1];
+        out[1] = roots8[2 * (degree / 4 - index)];
+    }
+    else if (index <= degree / 2)
+    {
+        /* -conj(z) = (-re, im) */
+        mo_complex_get_root(degree, roots8, degree / 2 - index, t);
+        out[0] = -t[0];
+        out[1] = -(-t[1]);
+    }
+    else if (index <= 3 * degree / 4)
+    {
+        mo_complex_get_root(degree, roots8, index - degree / 2, t);
+        out[0] = -t[0];
+        out[1] = -t[1];
+    }
+    else
+    {
+        mo_complex_get_root(degree, roots8, degree - index, t);
+        out[0] = t[0];
+        out[1] = -t[1];
+    }
+}
+
+mo_ckks_tables *mo_ckks_tables_create(int logn)
+{
+    /* SEAL/ckks.cpp:13-76 */
+    if (logn < 2 || logn > 20)
+    {
+        return NULL;
+    }
+    mo_ckks_tables *t = (mo_ckks_tables *)calloc(1, sizeof(*t));
+    const size_t n = (size_t)1 << logn;
+    t->logn = logn;
+    t->n = n;
+    t->slots = n >> 1;
+    t->index_map = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    t->root_powers = (double *)calloc(2 * n, sizeof(double));
+    t->inv_root_powers = (double *)calloc(2 * n, sizeof(double));
+    const uint64_t m = (uint64_t)n << 1;
+    uint64_t gen = 5, pos = 1;
+    for (size_t i = 0; i < t->slots; i++)
+    {
+        uint64_t index1 = (pos - 1) >> 1;
+        uint64_t index2 = (m - pos - 1) >> 1;
+        t->index_map[i] = reverse_bits32((uint32_t)index1, logn);
+        t->index_map[t->slots | i] = reverse_bits32((uint32_t)index2, logn);
+        pos *= gen;
+        pos &= (m - 1);
+    }
+    if (m >= 8)
+    {
+        /* SEAL/util/croots.cpp:18-42: polar(1.0, 2 * PI * i / degree) for i <= degree / 8 */
+        const double PI_ = 3.1415926535897932384626433832795028842;
+        const size_t cnt = (size_t)(m / 8 + 1);
+        double *roots8 = (double *)malloc(sizeof(double) * 2 * cnt);
+        for (size_t i = 0; i < cnt; i++)
+        {
+            /* std::polar(1.0, theta) = (cos(theta), sin(theta)); GCC at -O2 and above (the reference's
+             * Release build) merges the pair into ONE sincos call, and glibc's sincos does not return
+             * sin()'s bits for every argument (1 of 2049 entries differs at N = 2^13 with glibc 2.35),
+             * so call sincos explicitly rather than leave it to the optimiser */
+            double theta = 2 * PI_ * (double)i / (double)m, sn, cs;
+            sincos(theta, &sn, &cs);
+            roots8[2 * i] = 1.0 * cs;
+            roots8[2 * i + 1] = 1.0 * sn;
+        }
+        for (size_t i = 1; i < n; i++)
+        {
+            double z[2];
+            mo_complex_get_root((size_t)m, roots8, reverse_bits32((uint32_t)i, logn), &t->root_powers[2 * i]);
+            mo_complex_get_root((size_t)m, roots8, (size_t)reverse_bits32((uint32_t)(i - 1), logn) + 1, z);
+            t->inv_root_powers[2 * i] = z[0];
+            t->inv_root_powers[2 * i + 1] = -z[1];
+        }
+        free(roots8);
+    }
+    else
+    {
+        t->root_powers[2] = 0;
+        t->root_powers[3] = 1;
+        t->inv_root_powers[2] = 0;
+        t->inv_root_powers[3] = -1;
+    }
+    return t;
+}
+
+void mo_ckks_tables_free(mo_ckks_tables *t)
+{
+    if (t)
+    {
+        free(t->index_map);
+        free(t->root_powers);
+        free(t->inv_root_powers);
+        free(t);
+    }
+}
+
+/* std::complex<double> a * r, as libstdc++/libgcc evaluate it for finite operands */
+static inline void cmul(const double a[2], const double r[2], double out[2])
+{
+    double ac = a[0] * r[0], bd = a[1] * r[1], ad = a[0] * r[1], bc = a[1] * r[0];
+    out[0] = ac - bd;
+    out[1] = ad + bc;
+}
+
+void mo_fft_transform_from_rev(double *values, int log_n, const double *roots, const double *scalar)
+{
+    /* SEAL/util/dwthandler.h:202-356 with Arithmetic<complex<double>, complex<double>, double>
+     * (SEAL/ckks.h:46-81).  The reference's 4-way unrolling does not change any operation. */
+    const size_t n = (size_t)1 << log_n;
+    size_t gap = 1, m = n >> 1, root = 0;
+    double d[2];
+    for (; m > 1; m >>= 1)
+    {
+        size_t offset = 0;
+        for (size_t i = 0; i < m; i++)
+        {
+            const double *r = roots + 2 * (++root);
+            double *x = values + 2 * offset, *y = x + 2 * gap;
+            for (size_t j = 0; j < gap; j++, x += 2, y += 2)
+            {
+                double u0 = x[0], u1 = x[1], v0 = y[0], v1 = y[1];
+                x[0] = u0 + v0;
+                x[1] = u1 + v1;
+                d[0] = u0 - v0;
+                d[1] = u1 - v1;
+                cmul(d, r, y);
+            }
+            offset += gap << 1;
+        }
+        gap <<= 1;
+    }
+    const double *r = roots + 2 * (++root);
+    double *x = values, *y = x + 2 * gap;
+    if (scalar)
+    {
+        const double s = *scalar;
+        const double scaled_r[2] = { r[0] * s, r[1] * s };
+        for (size_t j = 0; j < gap; j++, x += 2, y += 2)
+        {
+            double u0 = x[0], u1 = x[1], v0 = y[0], v1 = y[1];
+            x[0] = (u0 + v0) * s;
+            x[1] = (u1 + v1) * s;
+            d[0] = u0 - v0;
+            d[1] = u1 - v1;
+            cmul(d, scaled_r, y);
+        }
+    }
+    else
+    {
+        for (size_t j = 0; j < gap; j++, x += 2, y += 2)
+        {
+            double u0 = x[0], u1 = x[1], v0 = y[0], v1 = y[1];
+            x[0] = u0 + v0;
+            x[1] = u1 + v1;
+            d[0] = u0 - v0;
+            d[1] = u1 - v1;
+            cmul(d, r, y);
+        }
+    }
+}
+
+void mo_fft_transform_to_rev(double *values, int log_n, const double *roots)
+{
+    /* SEAL/util/dwthandler.h:94-191, no scalar */
+    const size_t n = (size_t)1 << log_n;
+    size_t gap = n >> 1, m = 1, root = 0;
+    double v[2];
+    for (; m <= (n >> 1); m <<= 1)
+    {
+        size_t offset = 0;
+        for (size_t i = 0; i < m; i++)
+        {
+            const double *r = roots + 2 * (++root);
+            double *x = values + 2 * offset, *y = x + 2 * gap;
+            for (size_t j = 0; j < gap; j++, x += 2, y += 2)
+            {
+                double u0 = x[0], u1 = x[1];
+                cmul(y, r, v);
+                x[0] = u0 + v[0];
+                x[1] = u1 + v[1];
+                y[0] = u0 - v[0];
+                y[1] = u1 - v[1];
+            }
+            offset += gap << 1;
+        }
+        gap >>= 1;
+    }
+}
+
+#define MO_MAX_WORDS 64
+
+/* value mod q of a little-endian multi-word integer: what RNSBase::decompose (SEAL/util/rns.cpp,
+ * via modulo_uint, SEAL/util/uintarithsmallmod.h) leaves in each residue */
+static uint64_t modulo_words(const uint64_t *w, size_t count, const mo_modulus *m)
+{
+    if (count == 0)
+    {
+        return 0;
+    }
+    if (count == 1)
+    {
+        return mo_barrett_reduce_64(w[0], m);
+    }
+    uint64_t acc = mo_barrett_reduce_64(w[count - 1], m);
+    for (size_t i = count - 1; i-- > 0;)
+    {
+        uint64_t t[2] = { w[i], acc };
+        acc = mo_barrett_reduce_128(t, m);
+    }
+    return acc;
+}
+
+/* ckks.h:549-629 / ckks.cpp:129-211: residues of round()-ed coefficient `coeffd_in` */
+static void decompose_coeff(const mo_context *c, double coeffd_in, int bit_count, size_t L,
+                            const uint32_t *prime_index, uint64_t *out, size_t stride)
+{
+    const double two_pow_64 = pow(2.0, 64);
+    double coeffd = round(coeffd_in);
+    int is_negative = signbit(coeffd);
+    coeffd = fabs(coeffd);
+    for (size_t j = 0; j < L; j++)
+    {
+        const mo_modulus *q = &c->mods[prime_index ? prime_index[j] : j];
+        uint64_t r;
+        if (bit_count <= 64)
+        {
+            r = mo_barrett_reduce_64((uint64_t)coeffd, q);
+        }
+        else if (bit_count <= 128)
+        {
+            uint64_t w[2] = { (uint64_t)fmod(coeffd, two_pow_64), (uint64_t)(coeffd / two_pow_64) };
+            r = mo_barrett_reduce_128(w, q);
+        }
+        else
+        {
+            uint64_t w[MO_MAX_WORDS];
+            size_t cnt = 0;
+            double cd = coeffd;
+            while (cd >= 1 && cnt < MO_MAX_WORDS)
+            {
+                w[cnt++] = (uint64_t)fmod(cd, two_pow_64);
+                cd /= two_pow_64;
+            }
+            r = modulo_words(w, cnt, q);
+        }
+        out[j * stride] = is_negative ? mo_negate_uint_mod(r, q) : r;
+    }
+}
+
+int mo_ckks_encode(const mo_context *c, const mo_ckks_tables *t, const double *values, int is_complex,
+                   size_t count, size_t L, const uint32_t *prime_index, double scale, int total_bits,
+                   uint64_t *dst, int *max_coeff_bit_count)
+{
+    /* SEAL/ckks.h:457-637 */
+    const size_t n = t->n, slots = t->slots;
+    if (count > slots)
+    {
+        return -1;
+    }
+    if (scale <= 0 || ((int)log2(scale) + 1 >= total_bits))
+    {
+        return -2;
+    }
+    double *conj_values = (double *)calloc(2 * n, sizeof(double));
+    for (size_t i = 0; i < count; i++)
+    {
+        double re = is_complex ? values[2 * i] : values[i];
+        double im = is_complex ? values[2 * i + 1] : 0.0;
+        conj_values[2 * t->index_map[i]] = re;
+        conj_values[2 * t->index_map[i] + 1] = im;
+        conj_values[2 * t->index_map[i + slots]] = re;
+        conj_values[2 * t->index_map[i + slots] + 1] = -im;
+    }
+    double fix = scale / (double)n;
+    mo_fft_transform_from_rev(conj_values, t->logn, t->inv_root_powers, &fix);
+
+    double max_coeff = 0;
+    for (size_t i = 0; i < n; i++)
+    {
+        double a = fabs(conj_values[2 * i]);
+        max_coeff = a > max_coeff ? a : max_coeff;
+    }
+    int bits = (int)ceil(log2(max_coeff > 1.0 ? max_coeff : 1.0)) + 1;
+    if (max_coeff_bit_count)
+    {
+        *max_coeff_bit_count = bits;
+    }
+    if (bits >= total_bits)
+    {
+        free(conj_values);
+        return -3;
+    }
+    for (size_t i = 0; i < n; i++)
+    {
+        decompose_coeff(c, conj_values[2 * i], bits, L, prime_index, dst + i, n);
+    }
+    free(conj_values);
+    for (size_t j = 0; j < L; j++)
+    {
+        mo_ntt_negacyclic_harvey(dst + j * n, &c->tables[prime_index ? prime_index[j] : j]);
+    }
+    return 0;
+}
+
+int mo_ckks_encode_scalar(const mo_context *c, double value, size_t L, const uint32_t *prime_index,
+                          double scale, int total_bits, uint64_t *rows)
+{
+    /* SEAL/ckks.cpp:77-216 */
+    if (scale <= 0 || ((int)log2(scale) >= total_bits))
+    {
+        return -2;
+    }
+    value *= scale;
+    int coeff_bit_count = (int)log2(fabs(value)) + 2;
+    if (coeff_bit_count >= total_bits)
+    {
+        return -3;
+    }
+    decompose_coeff(c, value, coeff_bit_count, L, prime_index, rows, 1);
+    return 0;
 }

@@ -160,6 +160,40 @@ void mo_apply_galois_inplace(const mo_context *c, uint64_t *ct, size_t L, uint32
  * out [2][Lout][N] (NTT) */
 void mo_modraise(const mo_context *c, const uint64_t *in, size_t Lout, uint64_t *out);
 
+/* ---- SEAL/ckks.{h,cpp}: CKKSEncoder (floating point) ------
+ * Complex numbers are stored as interleaved (re, im) doubles.  Every floating-point operation is
+ * written out in the reference's order (std::complex<double> operator* is (ac - bd, ad + bc) with
+ * four separately rounded products, SEAL/ckks.h:46-81); build with -ffp-contract=off. */
+typedef struct
+{
+    int logn;
+    size_t n;                 /* poly_modulus_degree */
+    size_t slots;             /* n / 2 */
+    uint32_t *index_map;      /* matrix_reps_index_map_, generator 5  (ckks.cpp:34-52) */
+    double *root_powers;      /* [n][2]: get_root(bitrev(i))          (ckks.cpp:58-62) */
+    double *inv_root_powers;  /* [n][2]: conj(get_root(bitrev(i-1)+1))                 */
+} mo_ckks_tables;
+
+mo_ckks_tables *mo_ckks_tables_create(int logn);
+void mo_ckks_tables_free(mo_ckks_tables *t);
+/* ComplexRoots::get_root over roots8[i] = polar(1, 2 pi i / degree), i <= degree/8 (util/croots.cpp:18-75) */
+void mo_complex_get_root(size_t degree, const double *roots8, size_t index, double out[2]);
+/* DWTHandler<complex>::transform_from_rev / transform_to_rev (util/dwthandler.h:202-356 / 94-191) */
+void mo_fft_transform_from_rev(double *values, int log_n, const double *roots, const double *scalar);
+void mo_fft_transform_to_rev(double *values, int log_n, const double *roots);
+/* CKKSEncoder::encode_internal, vector form (ckks.h:457-637).  values: count reals (is_complex=0)
+ * or count (re,im) pairs; dst [L][N] in NTT form over context primes prime_index[0..L) (NULL =
+ * 0..L-1); total_bits = ContextData::total_coeff_modulus_bit_count() of that level.
+ * Returns 0, or -1 "values_size is too large", -2 "scale out of bounds", -3 "encoded values are
+ * too large".  *max_coeff_bit_count (optional) receives the branch selector of ckks.h:533. */
+int mo_ckks_encode(const mo_context *c, const mo_ckks_tables *t, const double *values, int is_complex,
+                   size_t count, size_t L, const uint32_t *prime_index, double scale, int total_bits,
+                   uint64_t *dst, int *max_coeff_bit_count);
+/* CKKSEncoder::encode_internal(double value, ...) (ckks.cpp:77-216): one residue per prime, which
+ * the reference replicates over the row.  rows[L].  Same return codes (-2, -3). */
+int mo_ckks_encode_scalar(const mo_context *c, double value, size_t L, const uint32_t *prime_index,
+                          double scale, int total_bits, uint64_t *rows);
+
 /* number of OpenMP threads the batch helpers below will use */
 int mo_max_threads(void);
 void mo_set_threads(int n);

@@ -115,6 +115,13 @@ def _declare(L):
         "mo_relinearize": (None, [vp, vp, vp, sz]),
         "mo_apply_galois_inplace": (None, [vp, vp, sz, C.c_uint32, vp]),
         "mo_modraise": (None, [vp, vp, sz, vp]),
+        "mo_ckks_tables_create": (vp, [C.c_int]),
+        "mo_ckks_tables_free": (None, [vp]),
+        "mo_fft_transform_from_rev": (None, [vp, C.c_int, vp, C.POINTER(C.c_double)]),
+        "mo_fft_transform_to_rev": (None, [vp, C.c_int, vp]),
+        "mo_ckks_encode": (C.c_int, [vp, vp, vp, C.c_int, sz, sz, vp, C.c_double, C.c_int, vp,
+                                     C.POINTER(C.c_int)]),
+        "mo_ckks_encode_scalar": (C.c_int, [vp, C.c_double, sz, vp, C.c_double, C.c_int, vp]),
         "mo_max_threads": (C.c_int, []),
         "mo_set_threads": (None, [C.c_int]),
     }
@@ -140,7 +147,7 @@ def mulop(operand, m):
 
 
 def ptr(a):
-    assert a.dtype == np.uint64 or a.dtype == np.uint32
+    assert a.dtype in (np.uint64, np.uint32, np.float64, np.complex128)
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
@@ -298,6 +305,80 @@ class Context:
         out = np.empty((2, Lout, self.n), dtype=np.uint64)
         lib().mo_modraise(self.h, ptr(ct), Lout, ptr(out))
         return out
+
+
+class CkksTablesStruct(C.Structure):
+    _fields_ = [("logn", C.c_int), ("n", C.c_size_t), ("slots", C.c_size_t),
+                ("index_map", C.POINTER(C.c_uint32)), ("root_powers", C.POINTER(C.c_double)),
+                ("inv_root_powers", C.POINTER(C.c_double))]
+
+
+class CkksEncoder:
+    """CKKSEncoder restatement (oracle/moai_oracle.h mo_ckks_*; SEAL/ckks.h:457-637, ckks.cpp:13-216)."""
+
+    ERRORS = {-1: "values_size is too large", -2: "scale out of bounds", -3: "encoded values are too large"}
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = lib().mo_ckks_tables_create(ctx.logn)
+        st = C.cast(self.h, C.POINTER(CkksTablesStruct)).contents
+        n = ctx.n
+        self.index_map = np.ctypeslib.as_array(st.index_map, shape=(n,)).copy()
+        self.root_powers = np.ctypeslib.as_array(st.root_powers, shape=(n, 2)).copy()
+        self.inv_root_powers = np.ctypeslib.as_array(st.inv_root_powers, shape=(n, 2)).copy()
+
+    def __del__(self):
+        try:
+            lib().mo_ckks_tables_free(self.h)
+        except Exception:
+            pass
+
+    def total_bits(self, L, prime_index=None):
+        idx = range(L) if prime_index is None else prime_index
+        prod = 1
+        for i in idx:
+            prod *= self.ctx.primes[int(i)]
+        return prod.bit_length()
+
+    def encode(self, values, L, scale, prime_index=None, return_bits=False):
+        """values: real or complex vector (<= n/2 entries).  Returns [L][N] NTT-form residues."""
+        v = np.asarray(values)
+        is_complex = np.iscomplexobj(v)
+        v = np.ascontiguousarray(v, dtype=np.complex128 if is_complex else np.float64)
+        out = np.zeros((L, self.ctx.n), dtype=np.uint64)
+        pi = None
+        if prime_index is not None:
+            pi_arr = np.ascontiguousarray(prime_index, dtype=np.uint32)
+            pi = ptr(pi_arr)
+        bits = C.c_int(0)
+        rc = lib().mo_ckks_encode(self.ctx.h, self.h, ptr(v), 1 if is_complex else 0, v.size, L, pi,
+                                  float(scale), self.total_bits(L, prime_index), ptr(out), C.byref(bits))
+        if rc:
+            raise ValueError(self.ERRORS[rc])
+        return (out, bits.value) if return_bits else out
+
+    def encode_scalar(self, value, L, scale, prime_index=None):
+        out = np.zeros(L, dtype=np.uint64)
+        pi = None
+        if prime_index is not None:
+            pi_arr = np.ascontiguousarray(prime_index, dtype=np.uint32)
+            pi = ptr(pi_arr)
+        rc = lib().mo_ckks_encode_scalar(self.ctx.h, float(value), L, pi, float(scale),
+                                         self.total_bits(L, prime_index), ptr(out))
+        if rc:
+            raise ValueError(self.ERRORS[rc])
+        return out
+
+    def fft_from_rev(self, z, scalar=None):
+        a = np.ascontiguousarray(z, dtype=np.complex128).copy()
+        s = C.byref(C.c_double(scalar)) if scalar is not None else None
+        lib().mo_fft_transform_from_rev(ptr(a), self.ctx.logn, ptr(self.inv_root_powers), s)
+        return a
+
+    def fft_to_rev(self, z):
+        a = np.ascontiguousarray(z, dtype=np.complex128).copy()
+        lib().mo_fft_transform_to_rev(ptr(a), self.ctx.logn, ptr(self.root_powers))
+        return a
 
 
 def galois_elt_from_step(logn, step, generator=5):

@@ -132,6 +132,12 @@ int moai_ct_multiply(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64
                      void *stream);
 /* Evaluator::ckks_square SEAL/evaluator.cpp:1223-1282: (x0^2, 2 x0 x1, x1^2) */
 int moai_ct_square(moai_ctx *ctx, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream);
+/* sum over j < count of ckks_multiply(x[j], y[j]) (evaluator.cpp:805-860) accumulated with add_inplace
+ * (:155-240): the inner loop of include/source/matrix_mul/Ct_ct_matrix_mul.hpp:33-42 and :117-131 in one pass.
+ * x, y: [count][2][L][N]; out: [3][L][N].  Same canonical residues as the reference's multiply-reduce-add
+ * sequence.  Primes of at most 61 bits (SEAL's own bound, util/defines.h:40). */
+int moai_ct_dot(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t count, size_t L,
+                void *stream);
 
 /*
  * Column-packed ciphertext x plaintext matrix product with scalar-encoded weights: the body of

@@ -301,6 +301,83 @@ __global__ __launch_bounds__(256) void ct_pt_matmul_kernel(MatmulArgs g)
     }
 }
 
+__device__ __forceinline__ void mac128(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
+{
+    uint64_t pl = a * b;
+    uint64_t ph = mulhi64(a, b);
+    lo += pl;
+    hi += ph + (lo < pl ? 1 : 0);
+}
+
+// sum_j x[j] (*) y[j] with (*) = ckks_multiply of two size-2 ciphertexts (SEAL/evaluator.cpp:805-860) and the sum
+// = add_inplace (:155-240): the inner loop of MOAI's ciphertext-ciphertext products
+// (include/source/matrix_mul/Ct_ct_matrix_mul.hpp:33-42, 117-131).  The reference reduces every product and
+// every sum; the canonical residues of the total do not depend on when the reductions happen, so the three
+// components are accumulated in 128 bits and folded every 16 terms (32 products below 2^122 in the middle
+// component).  HBM bound: 4 rows read per term, 3 written at the end.
+struct CtDotArgs
+{
+    const uint64_t *x; // [count][2][L][N]
+    const uint64_t *y; // [count][2][L][N]
+    uint64_t *out;     // [3][L][N]
+    const PrimeConst *pc;
+    uint32_t count, L, n2;
+};
+
+__global__ __launch_bounds__(256) void ct_dot_kernel(CtDotArgs g)
+{
+    const uint32_t prime = blockIdx.y;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.n2)
+    {
+        return;
+    }
+    const size_t rs = g.n2;
+    const size_t ct_stride = (size_t)2 * g.L * rs;
+    const ulonglong2 *__restrict__ x0 = reinterpret_cast<const ulonglong2 *>(g.x) + (size_t)prime * rs + i;
+    const ulonglong2 *__restrict__ y0 = reinterpret_cast<const ulonglong2 *>(g.y) + (size_t)prime * rs + i;
+    const size_t p1 = (size_t)g.L * rs; // second polynomial of a ciphertext
+    uint64_t lo[6], hi[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+    {
+        lo[k] = hi[k] = 0;
+    }
+    for (uint32_t j = 0; j < g.count; ++j)
+    {
+        const ulonglong2 a0 = x0[j * ct_stride], a1 = x0[j * ct_stride + p1];
+        const ulonglong2 b0 = y0[j * ct_stride], b1 = y0[j * ct_stride + p1];
+        mac128(lo[0], hi[0], a0.x, b0.x);
+        mac128(lo[1], hi[1], a0.y, b0.y);
+        mac128(lo[2], hi[2], a0.x, b1.x);
+        mac128(lo[2], hi[2], a1.x, b0.x);
+        mac128(lo[3], hi[3], a0.y, b1.y);
+        mac128(lo[3], hi[3], a1.y, b0.y);
+        mac128(lo[4], hi[4], a1.x, b1.x);
+        mac128(lo[5], hi[5], a1.y, b1.y);
+        if ((j & 15u) == 15u)
+        {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+            {
+                lo[k] = barrett128(lo[k], hi[k], q, cr0, cr1);
+                hi[k] = 0;
+            }
+        }
+    }
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)prime * rs + i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        ulonglong2 r;
+        r.x = barrett128(lo[2 * k], hi[2 * k], q, cr0, cr1);
+        r.y = barrett128(lo[2 * k + 1], hi[2 * k + 1], q, cr0, cr1);
+        o[(size_t)k * p1] = r;
+    }
+}
+
 static inline dim3 row_grid(const moai_ctx *c, size_t rows, uint32_t per_thread_chunks = 1)
 {
     uint32_t n2 = (uint32_t)(c->n >> 1);
@@ -532,6 +609,42 @@ extern "C" int moai_ct_multiply(moai_ctx *c, const uint64_t *x, const uint64_t *
 extern "C" int moai_ct_square(moai_ctx *c, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream)
 {
     return ct_mul(c, x, x, out, L, batch, stream, true);
+}
+
+extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t count, size_t L,
+                           void *stream)
+{
+    int rc = check_rows(c, count * 2, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (count == 0)
+    {
+        return set_error(MOAI_EINVAL, "empty sum");
+    }
+    if (!x || !y || !out)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    for (size_t r = 0; r < L; r++)
+    {
+        if (c->primes[r] >> 61)
+        {
+            return set_error(MOAI_ELOGIC, "lazy accumulation needs primes of at most 61 bits");
+        }
+    }
+    CtDotArgs g;
+    g.x = x;
+    g.y = y;
+    g.out = out;
+    g.pc = c->pc;
+    g.count = (uint32_t)count;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    hipLaunchKernelGGL(ct_dot_kernel, row_grid(c, L), dim3(256), 0, (hipStream_t)stream, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
 }
 
 extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,

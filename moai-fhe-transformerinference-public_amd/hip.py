@@ -47,6 +47,7 @@ SYMBOLS = {
     "moai_add_scalar_rows": (C.c_int, [vp, vp, u64p, vp, sz, sz, vp]),
     "moai_ct_multiply": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_square": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_ct_dot": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
     "moai_mod_drop": (C.c_int, [vp, vp, vp, sz, sz, sz, sz, vp]),
@@ -226,6 +227,9 @@ class Context:
 
     def ct_square(self, x, out, L, batch, stream=None):
         _check(lib().moai_ct_square(self.h, _ptr(x), _ptr(out), L, batch, stream))
+
+    def ct_dot(self, x, y, out, count, L, stream=None):
+        _check(lib().moai_ct_dot(self.h, _ptr(x), _ptr(y), _ptr(out), count, L, stream))
 
     def ct_pt_matmul(self, x, w, out, rows, cols, size, L, stream=None):
         _check(lib().moai_ct_pt_matmul(self.h, _ptr(x), _ptr(w), _ptr(out), rows, cols, size, L, stream))

@@ -4,7 +4,13 @@
 // moai_fused::ct_pt_matrix_mul_wo_pre replaces
 // include/source/matrix_mul/Ct_pt_matrix_mul.hpp:4-49 (and the "_large" variant :51-101, which differs
 // only in its OpenMP blocking): out[i] = rescale( sum_j multiply_plain(enc_X[j], encode(W[j][i])) ).
+//
+// moai_fused::ct_ct_matrix_mul_colpacking replaces include/source/matrix_mul/Ct_ct_matrix_mul.hpp:6-56
+// (Q K^T): out[i] = rescale(relinearize( sum_j multiply(X[j], rotate(W[j], i * num_batch)) )).
 #pragma once
+#include <algorithm>
+#include <map>
+
 #include "seal/seal.h"
 
 namespace moai_fused
@@ -70,6 +76,181 @@ namespace moai_fused
             output[c].scale() = scale; // Ct_pt_matrix_mul.hpp:41
         }
         seal_context.sync(); // w and the staging buffers go out of scope
+        return output;
+    }
+    namespace detail
+    {
+        // The key switches Evaluator::rotate_internal (SEAL/evaluator.cpp:2667-2722) performs for `steps`, as
+        // the list of Galois elements in the order it applies them: one element when the key exists,
+        // otherwise the non-adjacent form, each term through rotate_internal again, a term of N/2 skipped.
+        inline void rotation_sequence(const seal::SEALContext &context, const seal::GaloisKeys &keys, int steps,
+                                      std::vector<std::uint32_t> &out)
+        {
+            if (steps == 0)
+            {
+                return;
+            }
+            std::uint32_t elt = moai_galois_elt_from_step(context.device(), steps);
+            if (!elt)
+            {
+                throw std::invalid_argument("step count too large");
+            }
+            if (keys.has_key(elt))
+            {
+                out.push_back(elt);
+                return;
+            }
+            std::vector<int> naf_steps = seal::util::naf(steps);
+            if (naf_steps.size() == 1)
+            {
+                throw std::invalid_argument("Galois key not present");
+            }
+            for (int st : naf_steps)
+            {
+                if (static_cast<std::size_t>(std::abs(st)) != (context.n() >> 1))
+                {
+                    rotation_sequence(context, keys, st, out);
+                }
+            }
+        }
+    } // namespace detail
+
+    // Same arguments and the same ciphertexts, bit for bit, as MOAI's ct_ct_matrix_mul_colpacking.  What
+    // changes is the schedule: (1) the col_X columns travel as one batch, so every rotation is one batched
+    // key switch instead of col_X single ones; (2) rows whose rotation sequences share a prefix (3*256 =
+    // [-256, +1024] and 7*256 = [-256, +2048] both start with -256) share the prefix's result -- the same
+    // operations on the same operands give the same bits, so nothing but the count of key switches changes
+    // (355 -> 169 per column for 128 rows); (3) the col_X multiply + add_inplace pairs of a row are one
+    // moai_ct_dot pass; (4) relinearize and rescale run once over all rows.
+    inline std::vector<seal::Ciphertext> ct_ct_matrix_mul_colpacking(const std::vector<seal::Ciphertext> &enc_X,
+                                                                     const std::vector<seal::Ciphertext> &enc_W,
+                                                                     const seal::GaloisKeys &RotK,
+                                                                     const seal::RelinKeys &relin_keys,
+                                                                     const seal::SEALContext &seal_context, int col_X,
+                                                                     int row_X, int col_W, int row_W, int num_batch)
+    {
+        using namespace seal;
+        std::vector<Ciphertext> output(static_cast<std::size_t>(row_X));
+        if (col_X != col_W || row_X != row_W)
+        {
+            std::cout << "ERROR: bad dimensions of X or W. " << std::endl;
+            return output;
+        }
+        const double scale = enc_X[0].scale();
+        const parms_id_type pid = enc_X[0].parms_id();
+        auto cd = seal_context.get_context_data(pid);
+        if (!cd)
+        {
+            throw std::invalid_argument("encrypted1 is not valid for encryption parameters");
+        }
+        const std::size_t cols = static_cast<std::size_t>(col_X), rows = static_cast<std::size_t>(row_X);
+        for (std::size_t j = 0; j < cols; j++)
+        {
+            // the checks of Evaluator::multiply_inplace / add_inplace (evaluator.cpp:596-640, 155-180)
+            if (enc_X[j].parms_id() != pid || enc_W[j].parms_id() != pid)
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            }
+            if (enc_X[j].size() != 2 || enc_W[j].size() != 2)
+            {
+                throw std::logic_error("only size-2 ciphertexts are multiplied on the device");
+            }
+            if (!enc_X[j].is_ntt_form() || !enc_W[j].is_ntt_form())
+            {
+                throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+            }
+            if (enc_X[j].scale() != enc_X[0].scale() || enc_W[j].scale() != enc_W[0].scale())
+            {
+                throw std::invalid_argument("scale mismatch");
+            }
+        }
+        if (RotK.parms_id() != seal_context.key_parms_id())
+        {
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        }
+        if (relin_keys.parms_id() != seal_context.key_parms_id())
+        {
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        }
+        if (relin_keys.size() < 1)
+        {
+            throw std::invalid_argument("not enough relinearization keys");
+        }
+        if (!cd->next_context_data())
+        {
+            throw std::invalid_argument("end of modulus switching chain reached");
+        }
+        // scale of the products (evaluator.cpp:789-795, 904-908)
+        const double new_scale = enc_X[0].scale() * enc_W[0].scale();
+        if (new_scale <= 0 || (static_cast<int>(std::log2(new_scale)) >= cd->total_coeff_modulus_bit_count()))
+        {
+            throw std::invalid_argument("scale out of bounds");
+        }
+        // rotation sequences per row, rows ordered so that shared prefixes are adjacent
+        std::vector<std::vector<std::uint32_t>> seq(rows);
+        for (std::size_t i = 1; i < rows; i++)
+        {
+            detail::rotation_sequence(seal_context, RotK, static_cast<int>(i) * num_batch, seq[i]);
+        }
+        std::vector<std::size_t> order(rows);
+        for (std::size_t i = 0; i < rows; i++)
+        {
+            order[i] = i;
+        }
+        std::sort(order.begin(), order.end(), [&](std::size_t a, std::size_t b) { return seq[a] < seq[b]; });
+
+        const std::size_t L = cd->parms().coeff_modulus().size(), n = seal_context.n();
+        const std::size_t ct_words = 2 * L * n;
+        void *st = seal_context.stream();
+        moai_ctx *dev = seal_context.device();
+        util::DeviceArray dX(cols * ct_words, st), dW(cols * ct_words, st), d3(rows * 3 * L * n, st);
+        for (std::size_t j = 0; j < cols; j++)
+        {
+            util::hip_check(moai_memcpy_d2d(dX.get() + j * ct_words, enc_X[j].device_data(), ct_words * 8, st));
+            util::hip_check(moai_memcpy_d2d(dW.get() + j * ct_words, enc_W[j].device_data(), ct_words * 8, st));
+        }
+        // stack[d] = all columns of W after the first d + 1 key switches of the current sequence
+        std::vector<util::DeviceArray> stack;
+        std::vector<std::uint32_t> current;
+        for (std::size_t oi = 0; oi < rows; oi++)
+        {
+            const std::size_t i = order[oi];
+            const std::vector<std::uint32_t> &want = seq[i];
+            std::size_t common = 0;
+            while (common < current.size() && common < want.size() && current[common] == want[common])
+            {
+                common++;
+            }
+            current.resize(common);
+            while (stack.size() > common)
+            {
+                stack.pop_back();
+            }
+            for (std::size_t d = common; d < want.size(); d++)
+            {
+                const std::uint64_t *parent = d == 0 ? dW.get() : stack[d - 1].get();
+                stack.emplace_back(cols * ct_words, st);
+                util::hip_check(moai_memcpy_d2d(stack.back().get(), parent, cols * ct_words * 8, st));
+                const std::uint64_t *key = RotK.device_key(GaloisKeys::get_index(want[d]));
+                util::hip_check(moai_apply_galois(dev, stack.back().get(), L, want[d], key, cols, st));
+                current.push_back(want[d]);
+            }
+            const std::uint64_t *w = want.empty() ? dW.get() : stack.back().get();
+            util::hip_check(moai_ct_dot(dev, dX.get(), w, d3.get() + i * 3 * L * n, cols, L, st));
+        }
+        stack.clear();
+        util::DeviceArray d2(rows * ct_words, st), dres(rows * 2 * (L - 1) * n, st);
+        util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0), d2.get(), L, rows, st));
+        util::hip_check(moai_rescale(dev, d2.get(), dres.get(), 2, L, rows, st));
+        const parms_id_type next_id = cd->next_context_data()->parms_id();
+        for (std::size_t i = 0; i < rows; i++)
+        {
+            output[i].resize(seal_context, next_id, 2);
+            util::hip_check(moai_memcpy_d2d(output[i].device_data(), dres.get() + i * 2 * (L - 1) * n, 2 * (L - 1) * n * 8, st));
+            output[i].is_ntt_form() = true;
+            output[i].scale() = scale; // Ct_ct_matrix_mul.hpp:48
+        }
+        seal_context.sync(); // the staging buffers go out of scope
         return output;
     }
 } // namespace moai_fused

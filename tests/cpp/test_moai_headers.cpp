@@ -148,6 +148,25 @@ int main()
             }
             CHECK(err < 1e-4);
         }
+        // the batched / prefix-sharing replacement returns the very same ciphertexts
+        vector<Ciphertext> outf =
+            moai_fused::ct_ct_matrix_mul_colpacking(ea, eb, gal_keys, relin_keys, context, cols, rows, cols, rows, num_batch);
+        CHECK(outf.size() == out.size());
+        for (int i = 0; i < rows; i++)
+        {
+            CHECK(outf[i].parms_id() == out[i].parms_id());
+            CHECK(outf[i].scale() == out[i].scale());
+            CHECK(outf[i].download() == out[i].download());
+        }
+        // more rows than the toy product: rotations by 3, 5, 6, 7 batches need the NAF path and share prefixes
+        const int rows2 = 9, nb2 = 16;
+        vector<Ciphertext> o1 = ct_ct_matrix_mul_colpacking(ea, eb, gal_keys, relin_keys, context, cols, rows2, cols, rows2, nb2);
+        vector<Ciphertext> o2 =
+            moai_fused::ct_ct_matrix_mul_colpacking(ea, eb, gal_keys, relin_keys, context, cols, rows2, cols, rows2, nb2);
+        for (int i = 0; i < rows2; i++)
+        {
+            CHECK(o1[i].download() == o2[i].download());
+        }
     }
 
     // ---- gelu_v2 (degree-24 polynomial, the GELU the 12-layer run uses: test_full_scheme.hpp:886) ----

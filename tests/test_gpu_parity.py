@@ -146,6 +146,30 @@ def test_ct_multiply_square(moai, env12):
         assert (got[b] == octx.square(x[b], L)).all()
 
 
+@pytest.mark.parametrize("count,bits", [(1, [51, 46, 58]), (17, [61, 60, 40]), (64, [51, 46, 46]), (100, [61, 61])])
+def test_ct_dot_matches_multiply_add_chain(moai, count, bits):
+    # sum_j multiply(x[j], y[j]) as the reference issues it (Ct_ct_matrix_mul.hpp:33-42): one multiply and one
+    # add_inplace per term; all-(q-1) rows push the lazy accumulators to their bound (61-bit primes, 100 terms)
+    logn = 10
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    L = len(primes)
+    rng = np.random.default_rng(count)
+    x = O.uniform_rns(rng, primes, (count, 2), n)
+    y = O.uniform_rns(rng, primes, (count, 2), n)
+    for r, q in enumerate(primes):
+        x[:, :, r, :8] = q - 1
+        y[:, :, r, :8] = q - 1
+    want = octx.multiply(x[0], y[0], L)
+    for j in range(1, count):
+        want = octx.add(want, octx.multiply(x[j], y[j], L), 3, L)
+    dx, dy = up(moai, x), up(moai, y)
+    do = moai.DeviceBuffer(3 * L * n)
+    ctx.ct_dot(dx, dy, do, count, L)
+    assert (do.to_numpy((3, L, n)) == want).all()
+
+
 @pytest.mark.parametrize("L", [5, 4, 2])
 def test_rescale_and_drop(moai, env12, L):
     logn, primes, octx, ctx = env12

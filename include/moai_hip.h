@@ -138,6 +138,14 @@ int moai_ct_square(moai_ctx *ctx, const uint64_t *x, uint64_t *out, size_t L, si
  * sequence.  Primes of at most 61 bits (SEAL's own bound, util/defines.h:40). */
 int moai_ct_dot(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t count, size_t L,
                 void *stream);
+/* out[poly] = sum over t < terms of multiply_plain(x[x_index[t]][poly], p[p_index[t]]) (evaluator.cpp:2336-2373)
+ * accumulated with add_inplace: the inner loop of the baby-step / giant-step linear transforms of MOAI's
+ * bootstrapping (include/source/bootstrapping/Bootstrapper.cpp:2028-2046, 2095-2113) for a whole batch.
+ * x: operands, operand k = x + k * n_poly * L * N, each [n_poly][L][N] (n_poly = batch * ciphertext size);
+ * p: plaintexts in NTT form, [n_pt][L][N], shared by the batch; out: [n_poly][L][N]; x_index / p_index: host
+ * arrays.  terms <= 64.  Same canonical residues as the reference's multiply-reduce-add sequence. */
+int moai_ct_pt_dot(moai_ctx *ctx, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
+                   const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream);
 
 /*
  * Column-packed ciphertext x plaintext matrix product with scalar-encoded weights: the body of

@@ -378,6 +378,60 @@ __global__ __launch_bounds__(256) void ct_dot_kernel(CtDotArgs g)
     }
 }
 
+// out[poly] = sum_t x[xi[t]][poly] (.) p[pi[t]]: multiply_plain (SEAL/evaluator.cpp:2336-2373) of several
+// ciphertext operands with several NTT-form plaintexts, accumulated with add_inplace -- the inner loop of the
+// baby-step / giant-step linear transforms of MOAI's bootstrapping
+// (include/source/bootstrapping/Bootstrapper.cpp:2028-2046).  Operand k is the block x + k * n_poly * L * N
+// (a batch of ciphertexts, all polynomials of all of them: n_poly = batch * size); every plaintext is shared by
+// the whole batch.  Lazy 128-bit accumulation, folded every 32 terms; same canonical residues as the
+// reference's multiply-reduce-add sequence.
+constexpr int CTPT_MAX_TERMS = 64;
+struct CtPtDotArgs
+{
+    const uint64_t *x;
+    const uint64_t *p;   // [n_pt][L][N]
+    uint64_t *out;       // [n_poly][L][N]
+    const PrimeConst *pc;
+    uint32_t terms, L, n2, n_poly;
+    uint16_t xi[CTPT_MAX_TERMS];
+    uint16_t pi[CTPT_MAX_TERMS];
+};
+
+__global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
+{
+    const uint32_t row = blockIdx.y; // poly * L + prime
+    const uint32_t prime = row % g.L;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.n2)
+    {
+        return;
+    }
+    const size_t op_stride = (size_t)g.n_poly * g.L * g.n2;
+    const size_t pt_stride = (size_t)g.L * g.n2;
+    const ulonglong2 *__restrict__ xb = reinterpret_cast<const ulonglong2 *>(g.x) + (size_t)row * g.n2 + i;
+    const ulonglong2 *__restrict__ pb = reinterpret_cast<const ulonglong2 *>(g.p) + (size_t)prime * g.n2 + i;
+    uint64_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    for (uint32_t t = 0; t < g.terms; ++t)
+    {
+        const ulonglong2 a = xb[(size_t)g.xi[t] * op_stride];
+        const ulonglong2 b = pb[(size_t)g.pi[t] * pt_stride];
+        mac128(lo0, hi0, a.x, b.x);
+        mac128(lo1, hi1, a.y, b.y);
+        if ((t & 31u) == 31u)
+        {
+            lo0 = barrett128(lo0, hi0, q, cr0, cr1);
+            lo1 = barrett128(lo1, hi1, q, cr0, cr1);
+            hi0 = hi1 = 0;
+        }
+    }
+    ulonglong2 r;
+    r.x = barrett128(lo0, hi0, q, cr0, cr1);
+    r.y = barrett128(lo1, hi1, q, cr0, cr1);
+    reinterpret_cast<ulonglong2 *>(g.out)[(size_t)row * g.n2 + i] = r;
+}
+
 static inline dim3 row_grid(const moai_ctx *c, size_t rows, uint32_t per_thread_chunks = 1)
 {
     uint32_t n2 = (uint32_t)(c->n >> 1);
@@ -643,6 +697,56 @@ extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, ui
     g.L = (uint32_t)L;
     g.n2 = (uint32_t)(c->n >> 1);
     hipLaunchKernelGGL(ct_dot_kernel, row_grid(c, L), dim3(256), 0, (hipStream_t)stream, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
+                              const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream)
+{
+    int rc = check_rows(c, n_poly, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (terms == 0 || terms > CTPT_MAX_TERMS)
+    {
+        return set_error(MOAI_EINVAL, "between 1 and 64 terms per call");
+    }
+    if (n_poly == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!x || !p || !out || !x_index || !p_index)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    for (size_t r = 0; r < L; r++)
+    {
+        if (c->primes[r] >> 61)
+        {
+            return set_error(MOAI_ELOGIC, "lazy accumulation needs primes of at most 61 bits");
+        }
+    }
+    CtPtDotArgs g;
+    g.x = x;
+    g.p = p;
+    g.out = out;
+    g.pc = c->pc;
+    g.terms = (uint32_t)terms;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    g.n_poly = (uint32_t)n_poly;
+    for (size_t t = 0; t < terms; t++)
+    {
+        if (x_index[t] > 0xffffu || p_index[t] > 0xffffu)
+        {
+            return set_error(MOAI_EINVAL, "operand index out of range");
+        }
+        g.xi[t] = (uint16_t)x_index[t];
+        g.pi[t] = (uint16_t)p_index[t];
+    }
+    hipLaunchKernelGGL(ct_pt_dot_kernel, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
 }

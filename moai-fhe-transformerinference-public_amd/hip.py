@@ -48,6 +48,7 @@ SYMBOLS = {
     "moai_ct_multiply": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_square": (C.c_int, [vp, vp, vp, sz, sz, vp]),
     "moai_ct_dot": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
+    "moai_ct_pt_dot": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, vp]),
     "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
     "moai_mod_drop": (C.c_int, [vp, vp, vp, sz, sz, sz, sz, vp]),
@@ -230,6 +231,11 @@ class Context:
 
     def ct_dot(self, x, y, out, count, L, stream=None):
         _check(lib().moai_ct_dot(self.h, _ptr(x), _ptr(y), _ptr(out), count, L, stream))
+
+    def ct_pt_dot(self, x, p, out, x_index, p_index, n_poly, L, stream=None):
+        xi = (C.c_uint32 * len(x_index))(*[int(v) for v in x_index])
+        pi = (C.c_uint32 * len(p_index))(*[int(v) for v in p_index])
+        _check(lib().moai_ct_pt_dot(self.h, _ptr(x), _ptr(p), _ptr(out), xi, pi, len(x_index), n_poly, L, stream))
 
     def ct_pt_matmul(self, x, w, out, rows, cols, size, L, stream=None):
         _check(lib().moai_ct_pt_matmul(self.h, _ptr(x), _ptr(w), _ptr(out), rows, cols, size, L, stream))

@@ -9,6 +9,7 @@
 // (Q K^T): out[i] = rescale(relinearize( sum_j multiply(X[j], rotate(W[j], i * num_batch)) )).
 #pragma once
 #include <algorithm>
+#include <iostream>
 #include <map>
 
 #include "seal/seal.h"

@@ -170,6 +170,35 @@ def test_ct_dot_matches_multiply_add_chain(moai, count, bits):
     assert (do.to_numpy((3, L, n)) == want).all()
 
 
+@pytest.mark.parametrize("terms,bits", [(1, [51, 46]), (9, [61, 60, 40]), (40, [61, 61]), (64, [51, 46, 58])])
+def test_ct_pt_dot_matches_multiply_plain_add_chain(moai, terms, bits):
+    # sum_t multiply_plain(baby[xi[t]], plain[pi[t]]) as Bootstrapper::bsgs_linear_transform issues it
+    # (Bootstrapper.cpp:2028-2046): one multiply_plain and one add_inplace per term, for a batch of 3
+    logn = 10
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    L = len(primes)
+    rng = np.random.default_rng(terms)
+    n_ops, n_pt, B = 5, 7, 3
+    x = O.uniform_rns(rng, primes, (n_ops, B, 2), n)
+    p = O.uniform_rns(rng, primes, (n_pt,), n)
+    for r, q in enumerate(primes):
+        x[:, :, :, r, :8] = q - 1
+        p[:, r, :8] = q - 1
+    xi = rng.integers(0, n_ops, size=terms)
+    pi = rng.integers(0, n_pt, size=terms)
+    dx, dp = up(moai, x), up(moai, p)
+    do = moai.DeviceBuffer(B * 2 * L * n)
+    ctx.ct_pt_dot(dx, dp, do, xi, pi, B * 2, L)
+    got = do.to_numpy((B, 2, L, n))
+    for b in range(B):
+        want = octx.multiply_plain(x[xi[0], b], 2, L, p[pi[0]])
+        for t in range(1, terms):
+            want = octx.add(want, octx.multiply_plain(x[xi[t], b], 2, L, p[pi[t]]), 2, L)
+        assert (got[b] == want).all()
+
+
 @pytest.mark.parametrize("L", [5, 4, 2])
 def test_rescale_and_drop(moai, env12, L):
     logn, primes, octx, ctx = env12

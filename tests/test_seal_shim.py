@@ -45,10 +45,11 @@ def test_cpp_test_binaries_are_built():
     # built by __graft_entry__.build() (make -C tests/cpp); they travel to the GPU box with the snapshot
     assert os.path.exists(os.path.join(CPP, "test_seal_shim"))
     assert os.path.exists(os.path.join(CPP, "test_moai_headers"))
+    assert os.path.exists(os.path.join(CPP, "test_bootstrap_lt"))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers"])
+@pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers", "test_bootstrap_lt"])
 def test_cpp_binary_passes_on_gpu(binary):
     r = subprocess.run([os.path.join(CPP, binary)], cwd=CPP, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ALL PASS" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])

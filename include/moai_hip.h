@@ -80,7 +80,8 @@ int moai_stream_sync(void *stream);
 /* ---- negacyclic NTT ----------------------------------------------------------------------------
  * data: uint64[n_poly][L][N] in place.  Row (p, r) is transformed under context prime
  * prime_index[r] (host array of L entries) or prime r when prime_index is NULL.
- * forward:  natural order in -> bit-reversed order out, canonical [0,q)
+ * forward:  natural order in (values in [0, 4q), as the reference's lazy transform accepts) -> bit-reversed
+ *           order out, canonical [0,q)
  *           (ntt_negacyclic_harvey, SEAL/util/ntt.cpp:408-437; Evaluator::transform_to_ntt_inplace
  *           SEAL/evaluator.cpp:2468-2514)
  * inverse:  bit-reversed in -> natural out, scaled by N^-1, canonical

@@ -29,7 +29,10 @@ struct alignas(16) PrimeConst
     uint64_t cr1;      //                   high word
     Tw ninv;           // N^-1 mod q                     (NTTTables::inv_degree_modulo, ntt.cpp:290-296)
     Tw ninv_w1;        // N^-1 * inv_tw[1] mod q: last inverse stage with the scaling folded in
-    uint64_t pad[8];
+    uint64_t qd;       // bit pattern of (double) q          } FP64 arithmetic modes (modarith.cuh),
+    uint64_t qinv;     // bit pattern of RN(1.0 / q)         } meaningful when fp_mode != 0
+    uint64_t fp_mode;  // 0: integer only; M_FPN or M_FPR
+    uint64_t pad[5];
 };
 
 // Row -> context-prime map passed by value to kernels (rows of one RNS polynomial).
@@ -72,6 +75,10 @@ struct moai_ctx
     // workgroup read consecutive entries: [k][N/4096 tiles][15 slots][256 threads] (N >= 4096 only)
     moai::Tw *fwd_twb = nullptr;
     moai::Tw *inv_twb = nullptr;
+    // forward tables for the FP64 modes: {double w, double RN(w/q)} per entry, same indexing as fwd_tw /
+    // fwd_twb; rows of primes that have no FP64 mode are zero
+    moai::Tw *fwd_twf = nullptr;
+    moai::Tw *fwd_twfb = nullptr;
     moai::PrimeConst *pc = nullptr;    // [k]
     // inv_q_last_mod_q[l][i] = q_l^-1 mod q_i as Shoup operands, l in [1,k), i < l  (rns.cpp:769-775)
     moai::Tw *inv_qlast = nullptr;     // [k][k]

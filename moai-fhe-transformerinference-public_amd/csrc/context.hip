@@ -180,6 +180,15 @@ static void build_prime(int logn, uint64_t q, uint64_t psi, Tw *fwd, Tw *inv, Pr
         pc->cr0 = q0;
         pc->cr1 = q1;
     }
+    // FP64 arithmetic modes (modarith.cuh): q < 2^51; without intermediate reductions when sixteen stages
+    // starting from |x| <= q/2 and growing by at most 1.5 q each stay below 2^52
+    if (q < (1ull << 51))
+    {
+        const double qd = (double)q, qinv = 1.0 / (double)q;
+        memcpy(&pc->qd, &qd, 8);
+        memcpy(&pc->qinv, &qinv, 8);
+        pc->fp_mode = (25 * (unsigned __int128)q < ((unsigned __int128)1 << 52)) ? 2 : 3; // M_FPN : M_FPR
+    }
     uint64_t ninv = powmod((uint64_t)n % q, q - 2, q);
     pc->ninv = make_tw(ninv, q);
     pc->ninv_w1 = make_tw(mulmod(ninv, n > 1 ? inv[1].w : 1, q), q);
@@ -322,6 +331,35 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
             }
         }
     }
+    // FP64 forward tables: {double w, double RN(w / q)} in the two words of a Tw (modarith.cuh)
+    std::vector<Tw> fwdf, fwdfb;
+    if (logn >= 12)
+    {
+        fwdf.assign(k * n, Tw{ 0, 0 });
+        fwdfb.assign(k * nb, Tw{ 0, 0 });
+        auto to_fp = [](Tw t, uint64_t q) {
+            double w = (double)t.w, wq = (double)t.w / (double)q;
+            Tw o;
+            memcpy(&o.w, &w, 8);
+            memcpy(&o.wq, &wq, 8);
+            return o;
+        };
+        for (size_t p = 0; p < k; p++)
+        {
+            if (!c->pc_host[p].fp_mode)
+            {
+                continue;
+            }
+            for (size_t i = 0; i < n; i++)
+            {
+                fwdf[p * n + i] = to_fp(fwd[p * n + i], primes[p]);
+            }
+            for (size_t i = 0; i < nb; i++)
+            {
+                fwdfb[p * nb + i] = to_fp(fwdb[p * nb + i], primes[p]);
+            }
+        }
+    }
     // inv_qlast[l*k + i] = q_l^-1 mod q_i  (for all l != i; the rescale uses l = L-1 > i, the
     // key-switch mod-down uses l = k-1)
     c->inv_qlast_host.assign(k * k, Tw{ 0, 0 });
@@ -341,6 +379,10 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         (e = hipMalloc(&c->inv_tw, sizeof(Tw) * k * n)) != hipSuccess ||
         (e = hipMalloc(&c->pc, sizeof(PrimeConst) * k)) != hipSuccess ||
         (e = hipMalloc(&c->inv_qlast, sizeof(Tw) * k * k)) != hipSuccess ||
+        (nb && (e = hipMalloc(&c->fwd_twf, sizeof(Tw) * k * n)) != hipSuccess) ||
+        (nb && (e = hipMalloc(&c->fwd_twfb, sizeof(Tw) * k * nb)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->fwd_twf, fwdf.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->fwd_twfb, fwdfb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
         (nb && (e = hipMalloc(&c->fwd_twb, sizeof(Tw) * k * nb)) != hipSuccess) ||
         (nb && (e = hipMalloc(&c->inv_twb, sizeof(Tw) * k * nb)) != hipSuccess) ||
         (nb && (e = hipMemcpy(c->fwd_twb, fwdb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
@@ -369,6 +411,8 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
     (void)hipFree(c->inv_tw);
     (void)hipFree(c->pc);
     (void)hipFree(c->inv_qlast);
+    (void)hipFree(c->fwd_twf);
+    (void)hipFree(c->fwd_twfb);
     (void)hipFree(c->fwd_twb);
     (void)hipFree(c->inv_twb);
     for (auto &kv : c->ws)

@@ -20,6 +20,8 @@
 #include <cstdlib>
 
 #include "launch.h"
+#include <vector>
+
 #include "keyswitch_kernels.cuh"
 
 namespace moai {
@@ -382,7 +384,7 @@ static int check_level(const moai_ctx *c, size_t L, size_t polys)
 
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, hipStream_t s);
+                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, hipStream_t s);
 
 // number of output moduli whose digits are in flight at once: bounded by the scratch budget
 // (MOAI_KS_TMP_MB, default 2048 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
@@ -455,21 +457,19 @@ static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
            align256(ks_splits(c, L, batch) * batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
 }
 
-// which arithmetic discipline the primes of this context allow (keyswitch_kernels.cuh)
-static int ks_mode(const moai_ctx *c, size_t L)
+// which arithmetic the fused kernels use for output modulus `prime` (keyswitch_kernels.cuh): the forward
+// transform's mode, with the integer no-guard form only when the lazy digit may also enter the MAC unreduced
+static int ks_mode(const moai_ctx *c, uint32_t prime, size_t L)
 {
-    uint64_t qmax = 0;
-    for (uint64_t q : c->primes)
+    const int m = ntt_mode(c, prime);
+    if (m != M_NOGUARD)
     {
-        qmax = q > qmax ? q : qmax;
+        return m;
     }
-    if (!noguard_ok(qmax))
-    {
-        return 0;
-    }
-    // 36 q * q * L < 2^128: the lazy digit may enter the 128-bit accumulator unreduced
-    unsigned __int128 lim = (unsigned __int128)qmax * qmax;
-    return lim < ((~(unsigned __int128)0) / (36 * (unsigned __int128)(L ? L : 1))) ? 1 : 0;
+    // 36 q * q * L < 2^128
+    const uint64_t q = c->primes[prime];
+    unsigned __int128 lim = (unsigned __int128)q * q;
+    return lim < ((~(unsigned __int128)0) / (36 * (unsigned __int128)(L ? L : 1))) ? M_NOGUARD : M_GUARD;
 }
 
 template <int LOGN, int MODE>
@@ -480,7 +480,7 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     KsP1Args p1;
     p1.t = t;
     p1.tmp = tmp;
-    p1.tw = c->fwd_tw;
+    p1.tw = MODE >= M_FPN ? c->fwd_twf : c->fwd_tw;
     p1.pc = c->pc;
     p1.grp = grp;
     p1.L = (uint32_t)L;
@@ -492,7 +492,7 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.tmp = tmp;
     p2.key = key;
     p2.acc = acc;
-    p2.tw = c->fwd_tw;
+    p2.tw = MODE >= M_FPN ? c->fwd_twf : c->fwd_tw;
     p2.pc = c->pc;
     p2.grp = grp;
     p2.L = (uint32_t)L;
@@ -510,13 +510,15 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
 
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, hipStream_t s)
+                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, hipStream_t s)
 {
-    if (ks_mode(c, L))
+    switch (mode)
     {
-        return ks_fused_group_mode<LOGN, 1>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
+    case M_FPN: return ks_fused_group_mode<LOGN, M_FPN>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
+    case M_FPR: return ks_fused_group_mode<LOGN, M_FPR>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
+    case M_NOGUARD: return ks_fused_group_mode<LOGN, M_NOGUARD>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
+    default: return ks_fused_group_mode<LOGN, M_GUARD>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
     }
-    return ks_fused_group_mode<LOGN, 0>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
 }
 
 // target row block of ciphertext b starts at target + (b * target_stride_rows + target_off_rows) * N.
@@ -571,38 +573,60 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         {
             return set_error(MOAI_EINVAL, "batch too large for one launch");
         }
-        for (size_t I0 = 0; I0 <= L; I0 += G)
+        // output moduli (I = L stands for the special prime) ordered by arithmetic mode; a launch covers up to
+        // G of them, all of one mode
+        std::vector<uint16_t> order;
+        std::vector<int> order_mode;
+        for (int mode = M_FPR; mode >= M_GUARD; --mode)
         {
-            const size_t g = (L + 1 - I0) < G ? (L + 1 - I0) : G;
+            for (size_t Iidx = 0; Iidx <= L; ++Iidx)
+            {
+                const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+                if (ks_mode(c, prime, L) == mode)
+                {
+                    order.push_back((uint16_t)Iidx);
+                    order_mode.push_back(mode);
+                }
+            }
+        }
+        for (size_t o0 = 0; o0 < order.size();)
+        {
+            const int mode = order_mode[o0];
+            size_t g = 0;
+            while (o0 + g < order.size() && g < G && order_mode[o0 + g] == mode)
+            {
+                ++g;
+            }
             KsGroup grp;
             for (size_t i = 0; i < MOAI_MAX_RNS; ++i)
             {
-                size_t Iidx = I0 + (i < g ? i : 0);
+                size_t Iidx = order[o0 + (i < g ? i : 0)];
                 grp.prime[i] = (uint16_t)(Iidx == L ? k - 1 : Iidx);
                 grp.slot[i] = (uint16_t)Iidx;
             }
             switch (c->logn)
             {
             case 12:
-                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
+                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
                 break;
             case 13:
-                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
+                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
                 break;
             case 14:
-                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
+                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
                 break;
             case 15:
-                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
+                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
                 break;
             default:
-                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, splits, s);
+                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
                 break;
             }
             if (rc)
             {
                 return rc;
             }
+            o0 += g;
         }
     }
     else

@@ -33,9 +33,11 @@ struct KsP1Args
 };
 
 // work id -> (tile fastest, then group member, digit, ciphertext): neighbours read the same digit tile
-// MODE 0: reference discipline (guard per butterfly, digits normalised with two conditional subtracts)
-// MODE 1: every prime below 2^64/36 and 36 q^2 L < 2^128 (MOAI's chain): no guards, and the
-//         unreduced digit (< 33q) goes straight into the 128-bit MAC
+// MODE (modarith.cuh M_*), one per launch: the host groups the output moduli by the arithmetic they allow
+//   M_GUARD    reference discipline (guard per butterfly, digits normalised with two conditional subtracts)
+//   M_NOGUARD  prime below 2^64/36 and 36 q^2 L < 2^128: no guards, and the unreduced digit (< 33q) goes
+//              straight into the 128-bit MAC
+//   M_FPN/FPR  prime below 2^51: FP64 butterflies (tw = the FP64 table), canonical integer into the MAC
 template <int LOGN, int MODE>
 __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
 {
@@ -52,20 +54,39 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
     const PrimeConst *pc = a.pc + prime;
     const uint64_t *in = a.t + (((size_t)b * a.L + J) << LOGN);
     uint64_t *out = a.tmp + ((((size_t)b * a.G + g) * a.L + J) << LOGN);
+    if (MODE >= M_FPN)
+    {
+        // FP64 modes: the conversion to a double reduces modulo q_I on the way; a digit of 53 bits and more
+        // (its own prime is an integer-mode one) takes an integer Barrett step first.  Workgroup-uniform.
+        if (a.pc[J].q >> 52)
+        {
+            LoadBarrettFp op;
+            op.q = pc->q;
+            op.cr1 = pc->cr1;
+            op.qd = pc->qd;
+            op.qinv = pc->qinv;
+            fwd_strided_tile<LOGN, LoadBarrettFp, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+        }
+        else
+        {
+            LoadFp op;
+            op.qd = pc->qd;
+            op.qinv = pc->qinv;
+            fwd_strided_tile<LOGN, LoadFp, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+        }
+    }
     // digit J is canonical under prime J: it needs reducing only when that prime is the larger one
     // (SEAL/evaluator.cpp:2846-2854); the branch is workgroup-uniform
-    if (a.pc[J].q > pc->q)
+    else if (a.pc[J].q > pc->q)
     {
         LoadBarrett op;
         op.q = pc->q;
         op.cr1 = pc->cr1;
-        fwd_strided_tile<LOGN, LoadBarrett, (MODE != 0)>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds,
-                                                         threadIdx.x, op);
+        fwd_strided_tile<LOGN, LoadBarrett, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds, threadIdx.x, op);
     }
     else
     {
-        fwd_strided_tile<LOGN, LoadIdentity, (MODE != 0)>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds,
-                                                          threadIdx.x);
+        fwd_strided_tile<LOGN, LoadIdentity, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->q, pc->q2, lds, threadIdx.x);
     }
 }
 
@@ -138,7 +159,8 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
     const uint32_t prime = a.grp.prime[g];
     const uint32_t slot = a.grp.slot[g];
     const PrimeConst *pc = a.pc + prime;
-    const uint64_t q = pc->q, q2 = pc->q2;
+    const uint64_t q = pc->q;
+    const uint64_t bq1 = mode_q<MODE>(*pc), bq2 = mode_q2<MODE>(*pc); // the butterflies' (q, q2) under MODE
     const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
     const uint32_t tid0 = threadIdx.x;
 
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 if (!(j & half))
                 {
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))];
-                    ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
                 }
             }
         }
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 {
                     uint32_t t_ = (hi3 << 5) | ((uint32_t)j << 2) | lo2;
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
-                    ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
                 }
             }
         }
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 {
                     uint32_t t_ = (r << 3) | (uint32_t)j;
                     Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
-                    ct_bfly_t<(MODE != 0)>(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
                 }
             }
         }
@@ -242,21 +264,54 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
         const ulonglong2 *__restrict__ k1 =
             reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
+        if (MODE >= M_FPN)
         {
-            uint64_t vx = x[2 * c], vy = x[2 * c + 1];
-            if (MODE == 0)
+            // FP64 modes: the MAC stays on the FP64 pipe as well.  The digit is reduced to |v| <= q/2 so that
+            // h * (1/q) estimates the quotient of v * key within 0.9 (key canonical, below 2^51), each product
+            // is reduced exactly like a butterfly's, and the running sums stay far below 2^52.
+            const double qd = u2d(bq1), qinv = u2d(bq2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
             {
-                vx = csub(csub(vx, q2), q);
-                vy = csub(csub(vy, q2), q);
+                const double vx = fp_red(u2d(x[2 * c]), qd, qinv), vy = fp_red(u2d(x[2 * c + 1]), qd, qinv);
+                const ulonglong2 ka = k0[c];
+                const ulonglong2 kb = k1[c];
+                double s0 = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u64(ka.x), qd, qinv);
+                double s1 = u2d(lo0[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u64(ka.y), qd, qinv);
+                double s2 = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u64(kb.x), qd, qinv);
+                double s3 = u2d(lo1[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u64(kb.y), qd, qinv);
+                if (MODE == M_FPR || ((J - j0) & 15u) == 15u)
+                {
+                    // M_FPR: 2^52 / q may be as small as 2; M_FPN: sixteen terms of at most 0.9 q on top of q/2
+                    s0 = fp_red(s0, qd, qinv);
+                    s1 = fp_red(s1, qd, qinv);
+                    s2 = fp_red(s2, qd, qinv);
+                    s3 = fp_red(s3, qd, qinv);
+                }
+                lo0[2 * c] = d2u(s0);
+                lo0[2 * c + 1] = d2u(s1);
+                lo1[2 * c] = d2u(s2);
+                lo1[2 * c + 1] = d2u(s3);
             }
-            ulonglong2 ka = k0[c];
-            ulonglong2 kb = k1[c];
-            mac128r(lo0[2 * c], hi0[2 * c], vx, ka.x);
-            mac128r(lo0[2 * c + 1], hi0[2 * c + 1], vy, ka.y);
-            mac128r(lo1[2 * c], hi1[2 * c], vx, kb.x);
-            mac128r(lo1[2 * c + 1], hi1[2 * c + 1], vy, kb.y);
+        }
+        else
+        {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                uint64_t vx = x[2 * c], vy = x[2 * c + 1];
+                if (MODE == M_GUARD)
+                {
+                    vx = csub(csub(vx, bq2), q);
+                    vy = csub(csub(vy, bq2), q);
+                }
+                ulonglong2 ka = k0[c];
+                ulonglong2 kb = k1[c];
+                mac128r(lo0[2 * c], hi0[2 * c], vx, ka.x);
+                mac128r(lo0[2 * c + 1], hi0[2 * c + 1], vy, ka.y);
+                mac128r(lo1[2 * c], hi1[2 * c], vx, kb.x);
+                mac128r(lo1[2 * c + 1], hi1[2 * c + 1], vy, kb.y);
+            }
         }
         // no barrier here: the next digit writes buffer A, whose readers all passed the second barrier above,
         // and buffer B is written again only after the next first barrier
@@ -273,10 +328,21 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
     for (int c = 0; c < 4; ++c)
     {
         ulonglong2 r0, r1;
-        r0.x = barrett128(lo0[2 * c], hi0[2 * c], q, cr0, cr1);
-        r0.y = barrett128(lo0[2 * c + 1], hi0[2 * c + 1], q, cr0, cr1);
-        r1.x = barrett128(lo1[2 * c], hi1[2 * c], q, cr0, cr1);
-        r1.y = barrett128(lo1[2 * c + 1], hi1[2 * c + 1], q, cr0, cr1);
+        if (MODE >= M_FPN)
+        {
+            const double qd = u2d(bq1), qinv = u2d(bq2);
+            r0.x = fp_to_canonical(u2d(lo0[2 * c]), qd, qinv);
+            r0.y = fp_to_canonical(u2d(lo0[2 * c + 1]), qd, qinv);
+            r1.x = fp_to_canonical(u2d(lo1[2 * c]), qd, qinv);
+            r1.y = fp_to_canonical(u2d(lo1[2 * c + 1]), qd, qinv);
+        }
+        else
+        {
+            r0.x = barrett128(lo0[2 * c], hi0[2 * c], q, cr0, cr1);
+            r0.y = barrett128(lo0[2 * c + 1], hi0[2 * c + 1], q, cr0, cr1);
+            r1.x = barrett128(lo1[2 * c], hi1[2 * c], q, cr0, cr1);
+            r1.y = barrett128(lo1[2 * c + 1], hi1[2 * c + 1], q, cr0, cr1);
+        }
         o0[c] = r0;
         o1[c] = r1;
     }

@@ -5,6 +5,8 @@
 namespace moai {
 
 bool noguard_ok(uint64_t q);
+// arithmetic mode (modarith.cuh M_*) of the forward transform under a context prime
+int ntt_mode(const moai_ctx *c, uint32_t prime);
 int make_rowmap(const moai_ctx *c, size_t L, const uint32_t *prime_index, RowMap *out);
 int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse,
                hipStream_t s);

@@ -6,6 +6,8 @@
 
 namespace moai {
 
+int ntt_mode(const moai_ctx *c, uint32_t prime);
+
 static bool naive_requested()
 {
     static int v = -1;
@@ -17,21 +19,54 @@ static bool naive_requested()
     return v == 1;
 }
 
-template <int LOGN>
-static void launch_fwd(const NttArgs &base, bool noguard, hipStream_t s)
+static long env_long(const char *name, long dflt)
 {
-    NttArgs a = base;
-    constexpr uint32_t tpr_strided = 1u << (LOGN - 12);
-    a.total_work = a.n_poly * a.L * tpr_strided;
-    if (noguard)
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
+template <int LOGN, int MODE>
+static void launch_fwd_mode(const moai_ctx *c, NttArgs a, hipStream_t s)
+{
+    constexpr uint32_t tpr = 1u << (LOGN - 12);
+    a.total_work = a.n_poly * a.Lsel * tpr;
+    if (MODE >= M_FPN)
     {
-        hipLaunchKernelGGL((ntt_fwd_strided<LOGN, true>), dim3(a.total_work), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((ntt_fwd_contig<LOGN, true>), dim3(a.total_work), dim3(256), 0, s, a);
+        a.tw = c->fwd_twf;
+        a.twb = c->fwd_twfb;
     }
-    else
+    hipLaunchKernelGGL((ntt_fwd_strided<LOGN, MODE>), dim3(a.total_work), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((ntt_fwd_contig<LOGN, MODE>), dim3(a.total_work), dim3(256), 0, s, a);
+}
+
+// forward transform: the rows are split by the arithmetic their prime allows (ntt_mode) and every class
+// gets its own pair of launches
+template <int LOGN>
+static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
+{
+    for (int mode = M_GUARD; mode <= M_FPR; ++mode)
     {
-        hipLaunchKernelGGL((ntt_fwd_strided<LOGN, false>), dim3(a.total_work), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((ntt_fwd_contig<LOGN, false>), dim3(a.total_work), dim3(256), 0, s, a);
+        NttArgs a = base;
+        a.Lsel = 0;
+        for (uint32_t r = 0; r < a.L; ++r)
+        {
+            if (ntt_mode(c, a.rows.idx[r]) == mode)
+            {
+                a.selp.idx[a.Lsel] = a.rows.idx[r];
+                a.sel.idx[a.Lsel++] = (uint16_t)r;
+            }
+        }
+        if (a.Lsel == 0)
+        {
+            continue;
+        }
+        switch (mode)
+        {
+        case M_GUARD: launch_fwd_mode<LOGN, M_GUARD>(c, a, s); break;
+        case M_NOGUARD: launch_fwd_mode<LOGN, M_NOGUARD>(c, a, s); break;
+        case M_FPN: launch_fwd_mode<LOGN, M_FPN>(c, a, s); break;
+        default: launch_fwd_mode<LOGN, M_FPR>(c, a, s); break;
+        }
     }
 }
 
@@ -45,18 +80,25 @@ static void launch_inv(const NttArgs &base, hipStream_t s)
     hipLaunchKernelGGL(ntt_inv_strided<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
 }
 
-static long env_long(const char *name, long dflt)
-{
-    const char *e = getenv(name);
-    return e ? atol(e) : dflt;
-}
-
 } // namespace moai
 namespace moai {
 // 36 q < 2^64: forward butterflies may skip the per-stage guard (modarith.cuh ct_bfly_noguard)
 bool noguard_ok(uint64_t q)
 {
     return q < (~0ull) / 36;
+}
+
+// the arithmetic mode of the forward transform under context prime `prime` (modarith.cuh M_*):
+// FP64 below 2^51 (MOAI_NTT_FP=0 keeps everything on the integer units), else integer with or without guards
+int ntt_mode(const moai_ctx *c, uint32_t prime)
+{
+    static const long fp = env_long("MOAI_NTT_FP", 1);
+    const int m = (int)c->pc_host[prime].fp_mode;
+    if (fp && m)
+    {
+        return m;
+    }
+    return noguard_ok(c->primes[prime]) ? M_NOGUARD : M_GUARD;
 }
 
 // single-launch transform (ntt_coop); its queue state lives in a per-stream arena
@@ -141,6 +183,12 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     a.twb = inverse ? c->inv_twb : c->fwd_twb;
     a.pc = c->pc;
     a.rows = rows;
+    for (size_t r = 0; r < MOAI_MAX_RNS; ++r)
+    {
+        a.sel.idx[r] = (uint16_t)(r < L ? r : 0);
+        a.selp.idx[r] = rows.idx[r < L ? r : 0];
+    }
+    a.Lsel = (uint32_t)L;
     a.L = (uint32_t)L;
     a.n_poly = (uint32_t)n_poly;
     a.total_work = 0;
@@ -232,12 +280,6 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
             }
         }
     }
-    // every prime of this launch small enough for 16 unguarded stages (input < 4q, +2q per stage)?
-    bool noguard = !inverse;
-    for (size_t r = 0; r < L && noguard; ++r)
-    {
-        noguard = noguard_ok(c->primes[rows.idx[r]]);
-    }
 #define MOAI_NTT_CASE(LG)               \
     case LG:                            \
         if (inverse)                    \
@@ -246,7 +288,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
         }                               \
         else                            \
         {                               \
-            launch_fwd<LG>(a, noguard, s); \
+            launch_fwd<LG>(c, a, s);    \
         }                               \
         break;
     for (size_t p0 = 0; p0 < n_poly; p0 += chunk)

@@ -69,10 +69,25 @@ struct NttArgs
     const Tw *twb;             // same direction, per-thread order for the contiguous pass's last 4 stages
     const PrimeConst *pc;      // [k]
     RowMap rows;               // row r -> prime
+    RowMap sel;                // the rows this launch transforms: sel.idx[0..Lsel) (rows of one arithmetic mode)
+    RowMap selp;               // their primes: selp.idx[i] = rows.idx[sel.idx[i]]
     uint32_t L;
+    uint32_t Lsel;
     uint32_t n_poly;
     uint32_t total_work;       // grid size
 };
+
+// (q, q2) arguments of a tile function under MODE: the integer pair, or the bit patterns of (double q, 1/q)
+template <int MODE>
+__device__ __forceinline__ uint64_t mode_q(const PrimeConst &pc)
+{
+    return MODE >= M_FPN ? pc.qd : pc.q;
+}
+template <int MODE>
+__device__ __forceinline__ uint64_t mode_q2(const PrimeConst &pc)
+{
+    return MODE >= M_FPN ? pc.qinv : pc.q2;
+}
 
 // =====================================================================================================
 // forward, strided pass: stages 0 .. LOGN-9
@@ -96,8 +111,29 @@ struct LoadBarrett
     }
 };
 
+// FP64 modes: any integer below 2^53 -> the double holding its balanced residue (|.| <= q/2); serves both as
+// the plain load and as the "mod q_I" of the key switch
+struct LoadFp
+{
+    uint64_t qd, qinv;
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return d2u(fp_red(fp_from_u64(v), u2d(qd), u2d(qinv)));
+    }
+};
+
+// the same for integers of any size (a key-switch digit under a 52..61-bit prime): integer Barrett step first
+struct LoadBarrettFp
+{
+    uint64_t q, cr1, qd, qinv;
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return d2u(fp_red(fp_from_u64(barrett64(v, q, cr1)), u2d(qd), u2d(qinv)));
+    }
+};
+
 // one tile of the strided pass: reads row `inp`, writes row `outp` (may be the same row)
-template <int LOGN, class LoadOp = LoadIdentity, bool NOGUARD = false>
+template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD>
 __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
                                                  const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
                                                  const uint32_t tid, LoadOp op = LoadOp())
@@ -127,7 +163,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
             if (!(j & half))
             {
                 Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -158,7 +194,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
                 {
                     uint32_t t_ = (th << 4) | (uint32_t)j;
                     Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
-                    ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
@@ -180,18 +216,32 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
     }
 }
 
-template <int LOGN, bool NOGUARD = false>
+template <int LOGN, int MODE = M_GUARD>
 __global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
     const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t tile = w % TPR;
-    const uint32_t prow = w / TPR;
-    const uint32_t prime = a.rows.idx[prow % a.L];
-    uint64_t *rowp = a.data + ((size_t)prow << LOGN);
-    fwd_strided_tile<LOGN, LoadIdentity, NOGUARD>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), a.pc[prime].q,
-                                                  a.pc[prime].q2, lds, threadIdx.x);
+    const uint32_t srow = w / TPR;                 // over n_poly * Lsel selected rows
+    const uint32_t si = srow % a.Lsel;
+    // 16-bit kernarg entries arrive through a vector load: pin them back to scalars, or every address and
+    // modulus derived from them lives in VGPRs
+    const uint32_t r = __builtin_amdgcn_readfirstlane(a.sel.idx[si]);
+    const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[si]);
+    const PrimeConst &pc = a.pc[prime];
+    uint64_t *rowp = a.data + ((size_t)((srow / a.Lsel) * a.L + r) << LOGN);
+    if (MODE >= M_FPN)
+    {
+        LoadFp op;
+        op.qd = pc.qd;
+        op.qinv = pc.qinv;
+        fwd_strided_tile<LOGN, LoadFp, MODE>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), pc.qd, pc.qinv, lds, threadIdx.x, op);
+    }
+    else
+    {
+        fwd_strided_tile<LOGN, LoadIdentity, MODE>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), pc.q, pc.q2, lds, threadIdx.x);
+    }
 }
 
 // =====================================================================================================
@@ -207,9 +257,10 @@ struct StoreTile
     }
 };
 
-// NOGUARD: input below 20q (strided pass without guards), stages without guards, one Barrett step at
-// the end (cr1 = high word of floor(2^128/q)); otherwise the reference's [0,4q) discipline
-template <int LOGN, bool NOGUARD = false, class StoreOp = StoreTile>
+// M_NOGUARD: input below 20q (strided pass without guards), stages without guards, one Barrett step at
+// the end (cr1 = high word of floor(2^128/q)); M_GUARD: the reference's [0,4q) discipline; FP64 modes: doubles
+// in, canonical integers out (q, q2 carry the bit patterns of (double q, 1/q))
+template <int LOGN, int MODE = M_GUARD, class StoreOp = StoreTile>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
                                                 const Tw *__restrict__ twb, uint64_t cr1, StoreOp store)
@@ -238,7 +289,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             if (!(j & half))
             {
                 Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -267,7 +318,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             {
                 // slot = 2^(u-4) - 1 + (j >> (8-u)); consecutive threads read consecutive entries
                 Tw t = twbt[(((1u << (u - 4)) - 1u + (uint32_t)(j >> (8 - u))) << 8) + tid];
-                ct_bfly_t<NOGUARD>(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -276,7 +327,12 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     for (int c = 0; c < 8; ++c)
     {
         ulonglong2 v;
-        if (NOGUARD)
+        if (MODE >= M_FPN)
+        {
+            v.x = fp_to_canonical(u2d(x[2 * c]), u2d(q), u2d(q2));
+            v.y = fp_to_canonical(u2d(x[2 * c + 1]), u2d(q), u2d(q2));
+        }
+        else if (MODE == M_NOGUARD)
         {
             v.x = barrett64(x[2 * c], q, cr1);
             v.y = barrett64(x[2 * c + 1], q, cr1);
@@ -298,17 +354,17 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     }
 }
 
-template <int LOGN, bool NOGUARD = false>
+template <int LOGN, int MODE = M_GUARD>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
                                                 const Tw *__restrict__ twb, uint64_t cr1 = 0)
 {
     StoreTile st;
     st.out = reinterpret_cast<ulonglong2 *>(rowp + ((size_t)tile << 12));
-    fwd_contig_tile<LOGN, NOGUARD, StoreTile>(rowp, tile, tw, q, q2, lds2, tid, twb, cr1, st);
+    fwd_contig_tile<LOGN, MODE, StoreTile>(rowp, tile, tw, q, q2, lds2, tid, twb, cr1, st);
 }
 
-template <int LOGN, bool NOGUARD = false>
+template <int LOGN, int MODE = M_GUARD>
 __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -317,11 +373,12 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
     const uint32_t pol = w % a.n_poly;
     const uint32_t rest = w / a.n_poly;
     const uint32_t tile = rest % TPR;
-    const uint32_t r = rest / TPR;
-    const uint32_t prime = a.rows.idx[r];
-    fwd_contig_tile<LOGN, NOGUARD>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
-                                   a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x,
-                                   a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), a.pc[prime].cr1);
+    const uint32_t r = __builtin_amdgcn_readfirstlane(a.sel.idx[rest / TPR]);
+    const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[rest / TPR]);
+    const PrimeConst &pc = a.pc[prime];
+    fwd_contig_tile<LOGN, MODE>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
+                                mode_q<MODE>(pc), mode_q2<MODE>(pc), lds2, threadIdx.x,
+                                a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), pc.cr1);
 }
 
 // =====================================================================================================

@@ -27,8 +27,12 @@ k = len(primes)
 dev = torch.device("cuda")
 key = torch.randint(0, 1 << 45, (k - 1, 2, k, N), dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-for L, B in [(35, 1), (35, 8), (35, 64), (21, 64), (15, 64), (3, 64), (35, 256)]:
-    if len(sys.argv) > 1 and B > int(sys.argv[1]):
+cases = [(35, 1), (35, 8), (35, 64), (21, 64), (15, 64), (3, 64), (35, 256)]
+if "--only" in sys.argv:
+    i = sys.argv.index("--only")
+    cases = [(int(sys.argv[i + 1]), int(sys.argv[i + 2]))]
+for L, B in cases:
+    if "--only" not in sys.argv and len(sys.argv) > 1 and B > int(sys.argv[1]):
         continue
     ct = torch.randint(0, 1 << 45, (B, 2, L, N), dtype=torch.int64, device=dev)
     elt = ctx.galois_elt_from_step(1)

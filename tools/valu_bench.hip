@@ -77,6 +77,33 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
             B(w0, w1) B(w2, w3) B(w4, w5) B(w6, w7)
 #undef B
         }
+        else if (OP == 10)
+        {
+#define A(x) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(dy));
+            A(d0) A(d1) A(d2) A(d3) A(d4) A(d5) A(d6) A(d7)
+#undef A
+        }
+        else if (OP == 11)
+        {
+#define A(x) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x) : "v"(dy));
+            A(d0) A(d1) A(d2) A(d3) A(d4) A(d5) A(d6) A(d7)
+#undef A
+        }
+        else if (OP == 12)
+        {
+#define A(x) asm volatile("v_rndne_f64 %0, %0" : "+v"(x));
+            A(d0) A(d1) A(d2) A(d3) A(d4) A(d5) A(d6) A(d7)
+#undef A
+        }
+        else if (OP == 13)
+        {
+            // FP64 butterfly for primes below 2^50: v = y*w - rint(y*(w/q))*q exactly (FMA error-free
+            // product), x' = u + v, y' = u - v; 4 per iteration
+            const double q = 1125899906826241.0, tw = 288794978602139.0, twq = tw / q;
+#define B(x, yv) { double h = yv * (tw + dy); double l = __builtin_fma(yv, tw + dy, -h); double c = __builtin_rint(yv * twq); double v = __builtin_fma(-c, q, h) + l; double u = x; x = u + v; yv = u - v; }
+            B(d0, d1) B(d2, d3) B(d4, d5) B(d6, d7)
+#undef B
+        }
         else if (OP == 9)
         {
 #define A(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x) : "v"(y));
@@ -178,6 +205,10 @@ int main()
     run<6>("v_lshl_add_u64 (64-bit add)", 8, cus, d);
     run<7>("__umul64hi", 7, cus, d);
     run<8>("shoup butterfly (64-bit)", 4, cus, d);
+    run<10>("v_mul_f64", 8, cus, d);
+    run<11>("v_add_f64", 8, cus, d);
+    run<12>("v_rndne_f64", 8, cus, d);
+    run<13>("fp64 butterfly (q < 2^50)", 4, cus, d);
     // HBM copy reference
     {
         size_t bytes = (size_t)2 << 30;

@@ -230,6 +230,12 @@ int moai_total_coeff_modulus_bit_count(const moai_ctx *ctx, size_t L, const uint
  * inv_root_powers_ (host copy, N (re, im) pairs; ckks.cpp:54-71 via util/croots.cpp). */
 int moai_ckks_tables(moai_ctx *ctx, uint32_t *index_map, double *inv_root_powers);
 
+/* ---- tuning -------------------------------------------------------------------------------------------------------
+ * Overrides a performance knob for the whole process (same names as the environment variables read by the
+ * library, which it takes precedence over).  Results never depend on these.  Currently:
+ *   MOAI_KS_FP_MIN_ROWS  batch * L from which the key switch uses the FP64 arithmetic modes (default 256) */
+int moai_set_tuning(const char *name, long value);
+
 /* ---- measurement support -----------------------------------------------------------------------------------
  * Average duration in milliseconds of the NTT kernels of the last moai_ntt_* call recorded with
  * HIP events on the caller's stream is not provided here; callers time with their own events

@@ -30,6 +30,23 @@ const char *last_error()
     return g_err;
 }
 
+static std::mutex g_tuning_mu;
+static std::map<std::string, long> g_tuning;
+
+long tuning(const char *name, long dflt)
+{
+    {
+        std::lock_guard<std::mutex> g(g_tuning_mu);
+        auto it = g_tuning.find(name);
+        if (it != g_tuning.end())
+        {
+            return it->second;
+        }
+    }
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
 typedef unsigned __int128 u128;
 
 static inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q)
@@ -201,6 +218,17 @@ using namespace moai;
 extern "C" const char *moai_last_error(void)
 {
     return moai::last_error();
+}
+
+extern "C" int moai_set_tuning(const char *name, long value)
+{
+    if (!name)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    std::lock_guard<std::mutex> g(g_tuning_mu);
+    g_tuning[name] = value;
+    return MOAI_OK;
 }
 
 extern "C" int moai_version(void)

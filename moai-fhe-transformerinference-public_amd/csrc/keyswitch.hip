@@ -387,7 +387,7 @@ static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const u
                           size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, hipStream_t s);
 
 // number of output moduli whose digits are in flight at once: bounded by the scratch budget
-// (MOAI_KS_TMP_MB, default 2048 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
+// (MOAI_KS_TMP_MB, default 8192 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
 // one launch while large batches stay within a few GiB of workspace
 static size_t ks_group_size(const moai_ctx *c, size_t L, size_t batch)
 {
@@ -395,7 +395,7 @@ static size_t ks_group_size(const moai_ctx *c, size_t L, size_t batch)
     if (budget_mb < 0)
     {
         const char *e = getenv("MOAI_KS_TMP_MB");
-        budget_mb = e ? atol(e) : 2048;
+        budget_mb = e ? atol(e) : 8192;
         if (budget_mb < 1)
         {
             budget_mb = 1;
@@ -459,9 +459,13 @@ static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
 
 // which arithmetic the fused kernels use for output modulus `prime` (keyswitch_kernels.cuh): the forward
 // transform's mode, with the integer no-guard form only when the lazy digit may also enter the MAC unreduced
-static int ks_mode(const moai_ctx *c, uint32_t prime, size_t L)
+static int ks_mode(const moai_ctx *c, uint32_t prime, size_t L, bool allow_fp)
 {
-    const int m = ntt_mode(c, prime);
+    int m = ntt_mode(c, prime);
+    if (m >= M_FPN && !allow_fp)
+    {
+        m = noguard_ok(c->primes[prime]) ? M_NOGUARD : M_GUARD;
+    }
     if (m != M_NOGUARD)
     {
         return m;
@@ -575,6 +579,9 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         }
         // output moduli (I = L stands for the special prime) ordered by arithmetic mode; a launch covers up to
         // G of them, all of one mode
+        // every mode is one more pair of launches: a few ciphertexts at a low level are launch-bound and stay
+        // on the single integer group (measured: FP64 pays from about 256 digit rows per call)
+        const bool allow_fp = (long)(batch * L) >= tuning("MOAI_KS_FP_MIN_ROWS", 256);
         std::vector<uint16_t> order;
         std::vector<int> order_mode;
         for (int mode = M_FPR; mode >= M_GUARD; --mode)
@@ -582,7 +589,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             for (size_t Iidx = 0; Iidx <= L; ++Iidx)
             {
                 const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
-                if (ks_mode(c, prime, L) == mode)
+                if (ks_mode(c, prime, L, allow_fp) == mode)
                 {
                     order.push_back((uint16_t)Iidx);
                     order_mode.push_back(mode);

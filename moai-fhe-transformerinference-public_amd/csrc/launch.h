@@ -4,6 +4,8 @@
 
 namespace moai {
 
+// a tuning knob: the value set through moai_set_tuning, else the environment variable of that name, else dflt
+long tuning(const char *name, long dflt);
 bool noguard_ok(uint64_t q);
 // arithmetic mode (modarith.cuh M_*) of the forward transform under a context prime
 int ntt_mode(const moai_ctx *c, uint32_t prime);

@@ -61,6 +61,7 @@ SYMBOLS = {
     "moai_ckks_encode": (C.c_int, [vp, vp, C.c_int, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
     "moai_total_coeff_modulus_bit_count": (C.c_int, [vp, sz, C.POINTER(C.c_uint32)]),
     "moai_ckks_tables": (C.c_int, [vp, vp, vp]),
+    "moai_set_tuning": (C.c_int, [C.c_char_p, C.c_long]),
     "moai_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
     "moai_event_create": (C.c_int, [C.POINTER(vp)]),
     "moai_event_destroy": (C.c_int, [vp]),
@@ -308,6 +309,10 @@ class Context:
 
     def sync(self, stream=None):
         _check(lib().moai_stream_sync(stream))
+
+
+def set_tuning(name, value):
+    _check(lib().moai_set_tuning(name.encode(), int(value)))
 
 
 def device_info(device=0):

@@ -16,6 +16,15 @@ def up(m, a):
     return m.DeviceBuffer.from_numpy(a)
 
 
+@pytest.fixture(params=["fp64", "int64"])
+def ks_arith(request, moai):
+    """Key-switch tests run twice: with the FP64 arithmetic modes forced on for every prime below 2^51 (the
+    library only picks them from 256 digit rows per call) and with the integer units only."""
+    moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 0 if request.param == "fp64" else 1 << 40)
+    yield request.param
+    moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 256)
+
+
 @pytest.fixture(scope="module")
 def env12(moai):
     logn = 12
@@ -247,7 +256,7 @@ def test_galois_permute(moai, env12):
 
 
 @pytest.mark.parametrize("L", [4, 3, 1])
-def test_switch_key_relin_galois(moai, env12, L):
+def test_switch_key_relin_galois(moai, env12, L, ks_arith):
     logn, primes, octx, ctx = env12
     n, k = 1 << logn, len(primes)
     rng = np.random.default_rng(7 + L)
@@ -280,7 +289,7 @@ def test_switch_key_relin_galois(moai, env12, L):
 
 
 @pytest.mark.parametrize("bits", [[60, 50, 60, 61], [46, 58, 51, 58]])
-def test_switch_key_guarded_and_lazy_arithmetic(moai, bits):
+def test_switch_key_guarded_and_lazy_arithmetic(moai, bits, ks_arith):
     """60/61-bit primes take the guarded butterflies and normalised MAC; <= 58-bit chains (MOAI) the
     unguarded ones with the lazy 128-bit MAC.  Both must reproduce the oracle bit for bit."""
     logn = 13
@@ -313,7 +322,7 @@ def test_switch_key_guarded_and_lazy_arithmetic(moai, bits):
     assert (d.to_numpy(x.shape) == octx.ntt(x, k)).all()
 
 
-def test_keyswitch_decrypts(moai):
+def test_keyswitch_decrypts(moai, ks_arith):
     """semantic end-to-end: encrypt -> rotate on the GPU -> decrypt gives the rotated message."""
     from ckks_toy import ToyClient, galois_coeffs
     logn = 6
@@ -350,7 +359,7 @@ def test_modraise(moai, env12):
         assert (got[b] == octx.modraise(x[b], Lout)).all()
 
 
-def test_moai_chain_level_ops_n16(moai):
+def test_moai_chain_level_ops_n16(moai, ks_arith):
     """MOAI's real parameters (N = 2^16, the 36-prime chain): NTT on all 36 primes, rescale and one
     key switch at a low level, against the oracle."""
     logn = 16
@@ -478,7 +487,7 @@ def test_ct_pt_matmul_matches_multiply_plain_loop(moai, bits, rows, cols):
         assert (got[c] == acc).all(), c
 
 
-def test_key_switch_replays_from_a_hip_graph(moai):
+def test_key_switch_replays_from_a_hip_graph(moai, ks_arith):
     """the ~80 launches of one rotate captured once into a hipGraph (through torch's capture API, which
     is plumbing here) and replayed on new data: same bits as the oracle, one launch per call."""
     torch = pytest.importorskip("torch")

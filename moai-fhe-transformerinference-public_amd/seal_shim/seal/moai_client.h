@@ -771,6 +771,10 @@ namespace seal
             {
                 throw std::invalid_argument("encrypted must be in NTT form");
             }
+            if (encrypted.batch() != 1)
+            {
+                throw std::invalid_argument("packed ciphertext: moai_fused::unpack it before decrypting");
+            }
             const std::size_t L = encrypted.coeff_modulus_size(), n = context_.n();
             destination.scalar_rows_.clear();
             destination.parms_id_ = encrypted.parms_id();

@@ -29,7 +29,7 @@ namespace seal
         void negate_inplace(Ciphertext &encrypted) const
         {
             check_ct(encrypted, "encrypted");
-            hip(moai_negate(dev(), encrypted.device_data(), encrypted.device_data(), encrypted.size(),
+            hip(moai_negate(dev(), encrypted.device_data(), encrypted.device_data(), encrypted.size() * encrypted.batch(),
                             encrypted.coeff_modulus_size(), st()));
         }
         void negate(const Ciphertext &encrypted, Ciphertext &destination) const
@@ -41,7 +41,7 @@ namespace seal
             }
             check_ct(encrypted, "encrypted");
             like(destination, encrypted);
-            hip(moai_negate(dev(), encrypted.device_data(), destination.device_data(), encrypted.size(),
+            hip(moai_negate(dev(), encrypted.device_data(), destination.device_data(), encrypted.size() * encrypted.batch(),
                             encrypted.coeff_modulus_size(), st()));
         }
         void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const
@@ -64,7 +64,7 @@ namespace seal
                 check_pair(encrypted1, encrypted2);
                 like(destination, encrypted1);
                 hip(moai_add(dev(), encrypted1.device_data(), encrypted2.device_data(), destination.device_data(),
-                             encrypted1.size(), encrypted1.coeff_modulus_size(), st()));
+                             encrypted1.size() * encrypted1.batch(), encrypted1.coeff_modulus_size(), st()));
             }
             else
             {
@@ -111,7 +111,7 @@ namespace seal
                 check_pair(encrypted1, encrypted2);
                 like(destination, encrypted1);
                 hip(moai_sub(dev(), encrypted1.device_data(), encrypted2.device_data(), destination.device_data(),
-                             encrypted1.size(), encrypted1.coeff_modulus_size(), st()));
+                             encrypted1.size() * encrypted1.batch(), encrypted1.coeff_modulus_size(), st()));
             }
             else
             {
@@ -144,16 +144,20 @@ namespace seal
             {
                 throw std::invalid_argument("scale out of bounds");
             }
-            const std::size_t L = encrypted1.coeff_modulus_size();
+            if (encrypted1.batch() != encrypted2.batch())
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 pack different numbers of ciphertexts");
+            }
+            const std::size_t L = encrypted1.coeff_modulus_size(), B = encrypted1.batch();
             Ciphertext out;
-            out.resize(context_, encrypted1.parms_id(), 3);
+            out.resize_batch(context_, encrypted1.parms_id(), 3, B);
             if (&encrypted1 == &encrypted2 || encrypted1.device_data() == encrypted2.device_data())
             {
-                hip(moai_ct_square(dev(), encrypted1.device_data(), out.device_data(), L, 1, st()));
+                hip(moai_ct_square(dev(), encrypted1.device_data(), out.device_data(), L, B, st()));
             }
             else
             {
-                hip(moai_ct_multiply(dev(), encrypted1.device_data(), encrypted2.device_data(), out.device_data(), L, 1,
+                hip(moai_ct_multiply(dev(), encrypted1.device_data(), encrypted2.device_data(), out.device_data(), L, B,
                                      st()));
             }
             out.is_ntt_form() = true;
@@ -213,8 +217,9 @@ namespace seal
             }
             const std::size_t L = encrypted.coeff_modulus_size();
             Ciphertext out;
-            out.resize(context_, encrypted.parms_id(), 2);
-            hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0), out.device_data(), L, 1, st()));
+            out.resize_batch(context_, encrypted.parms_id(), 2, encrypted.batch());
+            hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0), out.device_data(), L,
+                                 encrypted.batch(), st()));
             out.is_ntt_form() = true;
             out.scale() = encrypted.scale();
             encrypted = std::move(out);
@@ -333,8 +338,8 @@ namespace seal
             auto next = cd->next_context_data();
             const std::size_t L = encrypted.coeff_modulus_size();
             Ciphertext out;
-            out.resize(context_, next->parms_id(), encrypted.size());
-            hip(moai_rescale(dev(), encrypted.device_data(), out.device_data(), encrypted.size(), L, 1, st()));
+            out.resize_batch(context_, next->parms_id(), encrypted.size(), encrypted.batch());
+            hip(moai_rescale(dev(), encrypted.device_data(), out.device_data(), encrypted.size(), L, encrypted.batch(), st()));
             out.is_ntt_form() = true;
             out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus().back().value());
             destination = std::move(out);
@@ -426,12 +431,12 @@ namespace seal
             if (plain.is_scalar())
             {
                 hip(moai_mul_scalar_rows(dev(), encrypted.device_data(), plain.scalar_rows().data(),
-                                         destination.device_data(), encrypted.size(), L, st()));
+                                         destination.device_data(), encrypted.size() * encrypted.batch(), L, st()));
             }
             else
             {
                 hip(moai_dyadic_mul(dev(), encrypted.device_data(), plain.device_data(), destination.device_data(),
-                                    encrypted.size(), 1, L, st()));
+                                    encrypted.size() * encrypted.batch(), 1, L, st()));
             }
             destination.scale() = new_scale;
         }
@@ -444,8 +449,8 @@ namespace seal
             {
                 throw std::invalid_argument("encrypted is already in NTT form");
             }
-            hip(moai_ntt_forward(dev(), encrypted.device_data(), encrypted.size(), encrypted.coeff_modulus_size(), nullptr,
-                                 st()));
+            hip(moai_ntt_forward(dev(), encrypted.device_data(), encrypted.size() * encrypted.batch(),
+                                 encrypted.coeff_modulus_size(), nullptr, st()));
             encrypted.is_ntt_form() = true;
         }
         void transform_to_ntt(const Ciphertext &encrypted, Ciphertext &destination) const
@@ -460,8 +465,8 @@ namespace seal
             {
                 throw std::invalid_argument("encrypted_ntt is not in NTT form");
             }
-            hip(moai_ntt_inverse(dev(), encrypted.device_data(), encrypted.size(), encrypted.coeff_modulus_size(), nullptr,
-                                 st()));
+            hip(moai_ntt_inverse(dev(), encrypted.device_data(), encrypted.size() * encrypted.batch(),
+                                 encrypted.coeff_modulus_size(), nullptr, st()));
             encrypted.is_ntt_form() = false;
         }
         void transform_from_ntt(const Ciphertext &encrypted, Ciphertext &destination) const
@@ -497,7 +502,7 @@ namespace seal
                 throw std::invalid_argument("CKKS encrypted must be in NTT form");
             }
             hip(moai_apply_galois(dev(), encrypted.device_data(), encrypted.coeff_modulus_size(), galois_elt,
-                                  galois_keys.device_key(GaloisKeys::get_index(galois_elt)), 1, st()));
+                                  galois_keys.device_key(GaloisKeys::get_index(galois_elt)), encrypted.batch(), st()));
         }
         void apply_galois(const Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
                           Ciphertext &destination, MemoryPoolHandle = MemoryPoolHandle()) const
@@ -640,7 +645,7 @@ namespace seal
         // give `dst` the shape and metadata of `src` without copying residues
         void like(Ciphertext &dst, const Ciphertext &src) const
         {
-            dst.resize(context_, src.parms_id(), src.size());
+            dst.resize_batch(context_, src.parms_id(), src.size(), src.batch());
             dst.is_ntt_form() = src.is_ntt_form();
             dst.scale() = src.scale();
         }
@@ -661,6 +666,10 @@ namespace seal
             {
                 throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
             }
+            if (e1.batch() != e2.batch())
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 pack different numbers of ciphertexts");
+            }
             if (e1.is_ntt_form() != e2.is_ntt_form())
             {
                 throw std::invalid_argument("NTT form mismatch");
@@ -678,6 +687,22 @@ namespace seal
             const std::size_t L = e1.coeff_modulus_size(), n = e1.poly_modulus_degree();
             const std::size_t min_size = std::min(e1.size(), e2.size());
             const std::size_t max_size = std::max(e1.size(), e2.size());
+            if (e1.batch() > 1)
+            {
+                if (min_size != max_size)
+                {
+                    throw std::logic_error("packed ciphertexts of different sizes cannot be added");
+                }
+                if (sub)
+                {
+                    hip(moai_sub(dev(), e1.device_data(), e2.device_data(), e1.device_data(), min_size * e1.batch(), L, st()));
+                }
+                else
+                {
+                    hip(moai_add(dev(), e1.device_data(), e2.device_data(), e1.device_data(), min_size * e1.batch(), L, st()));
+                }
+                return;
+            }
             if (e1.size() < max_size)
             {
                 // grow encrypted1, keeping its polynomials
@@ -733,6 +758,7 @@ namespace seal
                 throw std::invalid_argument("scale mismatch");
             }
             const std::size_t L = encrypted.coeff_modulus_size();
+            const std::size_t ct_words = encrypted.size() * L * encrypted.poly_modulus_degree();
             if (plain.is_scalar())
             {
                 std::vector<std::uint64_t> s = plain.scalar_rows();
@@ -745,15 +771,21 @@ namespace seal
                         s[r] = s[r] ? cm[r].value() - s[r] : 0;
                     }
                 }
-                hip(moai_add_scalar_rows(dev(), encrypted.device_data(), s.data(), encrypted.device_data(), 1, L, st()));
-            }
-            else if (sub)
-            {
-                hip(moai_sub(dev(), encrypted.device_data(), plain.device_data(), encrypted.device_data(), 1, L, st()));
+                for (std::size_t b = 0; b < encrypted.batch(); b++)
+                {
+                    std::uint64_t *c0 = encrypted.device_data() + b * ct_words;
+                    hip(moai_add_scalar_rows(dev(), c0, s.data(), c0, 1, L, st()));
+                }
             }
             else
             {
-                hip(moai_add(dev(), encrypted.device_data(), plain.device_data(), encrypted.device_data(), 1, L, st()));
+                // polynomial 0 of every packed ciphertext
+                for (std::size_t b = 0; b < encrypted.batch(); b++)
+                {
+                    std::uint64_t *c0 = encrypted.device_data() + b * ct_words;
+                    hip(sub ? moai_sub(dev(), c0, plain.device_data(), c0, 1, L, st())
+                            : moai_add(dev(), c0, plain.device_data(), c0, 1, L, st()));
+                }
             }
         }
 
@@ -773,8 +805,9 @@ namespace seal
             const std::size_t L = encrypted.coeff_modulus_size();
             auto target = context_.data_level(L - drop);
             Ciphertext out;
-            out.resize(context_, target->parms_id(), encrypted.size());
-            hip(moai_mod_drop(dev(), encrypted.device_data(), out.device_data(), encrypted.size(), L, drop, 1, st()));
+            out.resize_batch(context_, target->parms_id(), encrypted.size(), encrypted.batch());
+            hip(moai_mod_drop(dev(), encrypted.device_data(), out.device_data(), encrypted.size(), L, drop, encrypted.batch(),
+                              st()));
             out.is_ntt_form() = true;
             out.scale() = encrypted.scale();
             destination = std::move(out);

@@ -16,6 +16,55 @@
 
 namespace moai_fused
 {
+    // ---- packed ciphertexts -----------------------------------------------------------------------------------
+    // pack(): one seal::Ciphertext holding all of `cts` (same size, level, scale, NTT form) back to back.  Every
+    // Evaluator method applied to it performs the operation on each member with the device's batched kernels,
+    // so a per-ciphertext MOAI routine called on the pack (gelu_v2, exp, invert_sqrt, eval_odd_deg9_poly, ...)
+    // does the work of the OpenMP loop MOAI wraps around it, with the same result for every member bit for
+    // bit.  unpack() splits it again.
+    inline seal::Ciphertext pack(const std::vector<seal::Ciphertext> &cts, const seal::SEALContext &context)
+    {
+        using namespace seal;
+        if (cts.empty())
+        {
+            throw std::invalid_argument("nothing to pack");
+        }
+        const Ciphertext &f = cts[0];
+        for (auto &c : cts)
+        {
+            if (c.parms_id() != f.parms_id() || c.size() != f.size() || c.is_ntt_form() != f.is_ntt_form() ||
+                c.scale() != f.scale() || c.batch() != 1)
+            {
+                throw std::invalid_argument("pack: ciphertexts differ in level, size, form or scale");
+            }
+        }
+        Ciphertext out;
+        out.resize_batch(context, f.parms_id(), f.size(), cts.size());
+        out.is_ntt_form() = f.is_ntt_form();
+        out.scale() = f.scale();
+        const std::size_t words = f.size() * f.coeff_modulus_size() * f.poly_modulus_degree();
+        for (std::size_t b = 0; b < cts.size(); b++)
+        {
+            util::hip_check(moai_memcpy_d2d(out.device_data() + b * words, cts[b].device_data(), words * 8, context.stream()));
+        }
+        return out;
+    }
+    inline void unpack(const seal::Ciphertext &packed, const seal::SEALContext &context, std::vector<seal::Ciphertext> &cts)
+    {
+        using namespace seal;
+        const std::size_t B = packed.batch();
+        std::vector<Ciphertext> out(B);
+        const std::size_t words = packed.size() * packed.coeff_modulus_size() * packed.poly_modulus_degree();
+        for (std::size_t b = 0; b < B; b++)
+        {
+            out[b].resize(context, packed.parms_id(), packed.size());
+            out[b].is_ntt_form() = packed.is_ntt_form();
+            out[b].scale() = packed.scale();
+            util::hip_check(moai_memcpy_d2d(out[b].device_data(), packed.device_data() + b * words, words * 8, context.stream()));
+        }
+        cts = std::move(out);
+    }
+
     inline std::vector<seal::Ciphertext> ct_pt_matrix_mul_wo_pre(const std::vector<seal::Ciphertext> &enc_X,
                                                                  const std::vector<std::vector<double>> &W, int col_X,
                                                                  int col_W, int row_W, const seal::SEALContext &seal_context)

@@ -238,6 +238,19 @@ namespace seal
                 static DevicePool p;
                 return p;
             }
+            // Requests are rounded up to m * 2^k with m in 8..15 (at most 12.5 % slack), so that the blocks of
+            // ciphertexts a level or two apart -- what a rescale / mod-switch chain allocates and frees all the
+            // time -- are interchangeable instead of each size keeping its own free list.
+            static std::size_t size_class(std::size_t bytes)
+            {
+                if (bytes <= 4096)
+                {
+                    return 4096;
+                }
+                int top = 63 - __builtin_clzll(static_cast<unsigned long long>(bytes));
+                const std::size_t step = std::size_t(1) << (top - 3);
+                return (bytes + step - 1) & ~(step - 1);
+            }
             void *acquire(std::size_t bytes, void *stream)
             {
                 {
@@ -297,7 +310,7 @@ namespace seal
             DevicePool()
             {
                 const char *e = std::getenv("MOAI_POOL_CACHE_MB");
-                cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(65536)) << 20;
+                cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(131072)) << 20;
             }
             std::mutex mu_;
             std::map<std::pair<void *, std::size_t>, std::vector<void *>> free_;
@@ -355,7 +368,8 @@ namespace seal
                     words_ = words;
                     return;
                 }
-                void *p = DevicePool::instance().acquire(words * sizeof(std::uint64_t), stream);
+                const std::size_t alloc_words = DevicePool::size_class(words * sizeof(std::uint64_t)) / sizeof(std::uint64_t);
+                void *p = DevicePool::instance().acquire(alloc_words * sizeof(std::uint64_t), stream);
                 if (ptr_ && words_)
                 {
                     // ordered on `stream`; the old block goes back to the pool of its own stream and can only
@@ -371,7 +385,8 @@ namespace seal
                     DevicePool::instance().release(ptr_, cap_ * sizeof(std::uint64_t), stream_);
                 }
                 ptr_ = static_cast<std::uint64_t *>(p);
-                words_ = cap_ = words;
+                words_ = words;
+                cap_ = alloc_words;
                 stream_ = stream;
             }
             std::uint64_t *get() const
@@ -915,11 +930,12 @@ namespace seal
             parms_id_ = o.parms_id_;
             is_ntt_form_ = o.is_ntt_form_;
             size_ = o.size_;
+            batch_ = o.batch_;
             n_ = o.n_;
             L_ = o.L_;
             scale_ = o.scale_;
             stream_ = o.stream_;
-            data_.resize(o.size_ * o.L_ * o.n_, stream_);
+            data_.resize(o.batch_ * o.size_ * o.L_ * o.n_, stream_);
             if (data_.size())
             {
                 util::hip_check(moai_memcpy_d2d(data_.get(), o.data_.get(), data_.size() * 8, stream_));
@@ -928,6 +944,14 @@ namespace seal
         }
         void resize(const SEALContext &context, parms_id_type parms_id, std::size_t size)
         {
+            resize_batch(context, parms_id, size, 1);
+        }
+        void resize_batch(const SEALContext &context, parms_id_type parms_id, std::size_t size, std::size_t batch)
+        {
+            if (batch < 1)
+            {
+                throw std::invalid_argument("invalid batch");
+            }
             auto cd = context.get_context_data(parms_id);
             if (!cd)
             {
@@ -942,14 +966,27 @@ namespace seal
             n_ = cd->parms().poly_modulus_degree();
             L_ = cd->parms().coeff_modulus().size();
             size_ = size;
-            data_.resize(size_ * L_ * n_, stream_);
+            batch_ = batch;
+            data_.resize(batch_ * size_ * L_ * n_, stream_);
         }
         void release()
         {
             data_.release();
             size_ = 0;
+            batch_ = 1;
             parms_id_ = parms_id_zero;
         }
+        // ---- packed ciphertexts (moai_fused::pack / unpack, seal/moai_fused.h) -----------------------------
+        // A Ciphertext may hold `batch` ciphertexts of one size, level and scale back to back,
+        // [batch][size][L][N].  Every Evaluator method then performs its operation on each of them -- with the
+        // device's batched kernels instead of `batch` separate calls -- so MOAI's per-ciphertext routines
+        // (gelu_v2, exp, invert_sqrt, ...) process a whole batch when handed a packed ciphertext, unchanged.
+        // batch() is 1 for everything the reference API creates.
+        std::size_t batch() const noexcept
+        {
+            return batch_;
+        }
+
         std::size_t size() const noexcept
         {
             return size_;
@@ -995,7 +1032,7 @@ namespace seal
         // inside Bootstrapper::modraise_inplace, which maps to moai_modraise)
         std::vector<std::uint64_t> download() const
         {
-            std::vector<std::uint64_t> h(size_ * L_ * n_);
+            std::vector<std::uint64_t> h(batch_ * size_ * L_ * n_);
             if (!h.empty())
             {
                 util::hip_check(moai_memcpy_d2h(h.data(), data_.get(), h.size() * 8, stream_));
@@ -1005,7 +1042,7 @@ namespace seal
         }
         void upload(const std::vector<std::uint64_t> &h)
         {
-            if (h.size() != size_ * L_ * n_)
+            if (h.size() != batch_ * size_ * L_ * n_)
             {
                 throw std::invalid_argument("size mismatch");
             }
@@ -1030,6 +1067,7 @@ namespace seal
         parms_id_type parms_id_ = parms_id_zero;
         bool is_ntt_form_ = false;
         std::size_t size_ = 0, n_ = 0, L_ = 0;
+        std::size_t batch_ = 1;
         double scale_ = 1.0;
         util::DeviceArray data_;
         void *stream_ = nullptr;

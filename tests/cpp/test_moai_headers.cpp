@@ -1,5 +1,5 @@
 // test_moai_headers.cpp -- MOAI's own headers (include/source/matrix_mul/*.hpp,
-// include/source/non_linear_func/gelu_others.hpp), included UNCHANGED from the reference checkout at
+// include/source/non_linear_func/{gelu_others,layernorm}.hpp), included UNCHANGED from the reference checkout at
 // build time, compiled against the seal:: shim and run on the GPU at reduced sizes.  The flows follow
 // the reference's drivers (include/test/matrix_mul/test_ct_pt_matrix_mul.hpp:4-147,
 // test_ct_ct_matrix_mul.hpp:4-209) and, unlike them, assert on the decrypted result.
@@ -20,6 +20,7 @@
 #include "Ct_pt_matrix_mul.hpp"
 #include "Ct_ct_matrix_mul.hpp"
 #include "gelu_others.hpp"
+#include "layernorm.hpp"
 
 #include "seal/moai_fused.h"
 
@@ -192,6 +193,89 @@ int main()
         }
         printf("gelu_v2 max |error| vs exact GELU on [-3,3]: %.3e\n", err);
         CHECK(err < 5e-2);
+    }
+
+    // ---- packed ciphertexts: MOAI's per-ciphertext routines on a whole batch at once ------------------------
+    // gelu_v2 (gelu_others.hpp:4-153) and invert_sqrt (layernorm.hpp:145-155, via initGuess / newtonIter /
+    // goldSchmidtIter) are compiled once, unchanged; handed a pack they must return, for every member, the
+    // very ciphertext the per-ciphertext call returns.
+    {
+        Encryptor encryptor(context, pk);
+        const int B = 5;
+        vector<Ciphertext> xs(B);
+        for (int b = 0; b < B; b++)
+        {
+            vector<double> v(slots);
+            for (size_t s = 0; s < slots; s++)
+                v[s] = -2.0 + 0.37 * b + 3.0 * (double)s / (double)slots;
+            Plaintext p;
+            encoder.encode(v, scale, p);
+            encryptor.encrypt(p, xs[b]);
+        }
+        Ciphertext packed = moai_fused::pack(xs, context);
+        CHECK(packed.batch() == (size_t)B);
+        Ciphertext gp = gelu_v2(packed, context, relin_keys, sk);
+        vector<Ciphertext> gs;
+        moai_fused::unpack(gp, context, gs);
+        CHECK(gs.size() == (size_t)B);
+        for (int b = 0; b < B; b++)
+        {
+            Ciphertext g1 = gelu_v2(xs[b], context, relin_keys, sk);
+            CHECK(g1.parms_id() == gs[b].parms_id());
+            CHECK(g1.scale() == gs[b].scale());
+            CHECK(g1.download() == gs[b].download());
+        }
+        // 1/sqrt(x) on [20, 60]: linear initial guess, one Newton and one Goldschmidt iteration
+        for (int b = 0; b < B; b++)
+        {
+            vector<double> v(slots);
+            for (size_t s = 0; s < slots; s++)
+                v[s] = 20.0 + 7.0 * b + 10.0 * (double)s / (double)slots;
+            Plaintext p;
+            encoder.encode(v, scale, p);
+            encryptor.encrypt(p, xs[b]);
+        }
+        packed = moai_fused::pack(xs, context);
+        Ciphertext ip = invert_sqrt(packed, 1, 1, context, relin_keys);
+        moai_fused::unpack(ip, context, gs);
+        for (int b = 0; b < B; b++)
+        {
+            Ciphertext i1 = invert_sqrt(xs[b], 1, 1, context, relin_keys);
+            CHECK(i1.parms_id() == gs[b].parms_id());
+            CHECK(i1.download() == gs[b].download());
+        }
+        // rotations of a pack: NAF path included
+        Ciphertext rp = packed;
+        evaluator.rotate_vector_inplace(rp, 3, gal_keys);
+        moai_fused::unpack(rp, context, gs);
+        for (int b = 0; b < B; b++)
+        {
+            Ciphertext r1;
+            evaluator.rotate_vector(xs[b], 3, gal_keys, r1);
+            CHECK(r1.download() == gs[b].download());
+        }
+        // a pack cannot be decrypted or mixed with a single ciphertext
+        bool threw = false;
+        try
+        {
+            Plaintext p;
+            decryptor.decrypt(packed, p);
+        }
+        catch (const std::invalid_argument &)
+        {
+            threw = true;
+        }
+        CHECK(threw);
+        threw = false;
+        try
+        {
+            evaluator.add_inplace(packed, xs[0]);
+        }
+        catch (const std::invalid_argument &)
+        {
+            threw = true;
+        }
+        CHECK(threw);
     }
 
     if (!g_fail)

@@ -161,3 +161,35 @@ def test_error_codes():
         enc.encode(np.full(32, 1e12), 2, 2.0**30)
     with pytest.raises(ValueError, match="encoded values are too large"):
         enc.encode_scalar(1e12, 2, 2.0**30)
+
+
+def test_config1_plumbing_on_the_cpu_path():
+    """BASELINE.json configs[0] / SURVEY.md 8(d) config 1, on the CPU oracle end to end: N = 8192, primes
+    {60, 40, 60} from CoeffModulus::Create, scale 2^40, v[i] = i * 1e-3, weight 0.5:
+    encode -> encrypt -> multiply_plain -> rescale_to_next -> decrypt -> decode; out[1000] = 0.5, chain index 0."""
+    from ckks_toy import ToyClient
+
+    logn, n = 13, 8192
+    primes = O.coeff_modulus_create(n, [60, 40, 60])
+    assert primes == [1152921504606748673, 1099511480321, 1152921504606830593]
+    ctx = O.Context(logn, primes)
+    enc = O.CkksEncoder(ctx)
+    cl = ToyClient(ctx, seed=11)
+    L, scale = 2, 2.0**40  # two data primes; the third is the key-switching prime
+    v = np.arange(n // 2) * 1e-3
+    ct = cl.encrypt_zero_symmetric(L)
+    m = enc.encode(v, L, scale)
+    for i in range(L):
+        ct[0, i] = (ct[0, i] + m[i]) % np.uint64(primes[i])
+    w = enc.encode_scalar(0.5, L, scale)  # encoder.encode(0.5, parms_id, scale, plain): constant rows
+    plain = np.stack([np.full(n, w[i], dtype=np.uint64) for i in range(L)])
+    prod = ctx.multiply_plain(ct, 2, L, plain)
+    out = ctx.rescale(prod, 2, L)  # [2][1][N]: chain index 0
+    assert out.shape == (2, L - 1, n)
+    new_scale = scale * scale / primes[L - 1]
+    coeffs = cl.decrypt(out, 2, L - 1)
+    # decode with the oracle's forward transform (CKKSEncoder::decode_internal, SEAL/ckks.h:644-760)
+    z = np.array([c / new_scale for c in coeffs], dtype=np.complex128)
+    slots = enc.fft_to_rev(z)[enc.index_map[: n // 2]]
+    assert abs(slots[1000].real - 0.5) < 1e-5
+    assert np.max(np.abs(slots.real - 0.5 * v)) < 1e-5 and np.max(np.abs(slots.imag)) < 1e-5

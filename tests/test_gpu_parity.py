@@ -433,6 +433,17 @@ def test_empty_and_degenerate_calls(moai, env12):
         ctx.add(d, d, d, 1, len(primes) + 1)  # more rows than the context has primes
     with pytest.raises(moai.MoaiError):
         ctx.switch_key(d, d, d, len(primes), 1)  # L exceeds the key's decomposition size
+    # the fused sums: an empty sum and more than 64 terms are refused, a batch of zero polynomials is a no-op
+    with pytest.raises(moai.MoaiError, match="empty sum"):
+        ctx.ct_dot(d, d, d, 0, 1)
+    with pytest.raises(moai.MoaiError, match="terms"):
+        ctx.ct_pt_dot(d, d, d, [0] * 65, [0] * 65, 1, 1)
+    with pytest.raises(moai.MoaiError, match="terms"):
+        ctx.ct_pt_dot(d, d, d, [], [], 1, 1)
+    ctx.ct_pt_dot(d, d, d, [0], [0], 0, 1)
+    assert (d.to_numpy(x.shape) == octx.ntt(x, 1)).all()
+    with pytest.raises(moai.MoaiError):
+        moai.hip._check(moai.hip.lib().moai_set_tuning(None, 1))
 
 
 def test_coop_single_launch_ntt_agrees(moai):

@@ -223,6 +223,14 @@ int moai_modraise(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t L_out
 int moai_ckks_encode(moai_ctx *ctx, const double *values, int is_complex, size_t values_size, size_t n_batch,
                      uint64_t *dst, size_t L, const uint32_t *prime_index, double scale, double *max_coeff,
                      void *stream);
+/* The same for vectors of the form MOAI's masked matrix products encode
+ * (include/source/matrix_mul/Ct_pt_matrix_mul.hpp:124-146): values[b][s] = constants[b] where mask[s] == 1, else
+ * 0, for s < mask_size (the rest zero-padded).  constants: device, [n_batch] doubles; mask: device, [mask_size]
+ * int32 (MOAI's bias_vec).  Saves building and uploading n_batch * N/2 doubles; same residues as
+ * moai_ckks_encode on the expanded vectors. */
+int moai_ckks_encode_masked(moai_ctx *ctx, const double *constants, const int32_t *mask, size_t mask_size,
+                            size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index, double scale,
+                            double *max_coeff, void *stream);
 /* ContextData::total_coeff_modulus_bit_count (SEAL/context.cpp:169-173): significant bits of the product of
  * the L primes; 0 on error. */
 int moai_total_coeff_modulus_bit_count(const moai_ctx *ctx, size_t L, const uint32_t *prime_index);

@@ -39,6 +39,7 @@ struct EncArgs
     uint32_t logn;
     uint32_t values_size;
     uint32_t is_complex;
+    const int32_t *mask; // masked-constant form: values[b][s] = mask[s] == 1 ? values[b] : 0 (values holds one double per vector)
     double fix; // scale / N
 };
 
@@ -83,13 +84,22 @@ __global__ __launch_bounds__(256) void ckks_fft_contig(EncArgs g)
 
     // conj_values[matrix_reps_index_map_[i]] = values[i], [.. i + slots] = conj(values[i]) (ckks.h:505-510),
     // read through the inverse map so that the writes are the contiguous side
-    const double *vals = g.values + (size_t)b * g.values_size * (g.is_complex ? 2 : 1);
+    const double *vals = g.mask ? g.values + b : g.values + (size_t)b * g.values_size * (g.is_complex ? 2 : 1);
     for (uint32_t k = tid; k < tile; k += 256)
     {
         uint32_t s = g.src_map[base + k];
         uint32_t slot = s & (slots - 1);
         double r = 0.0, i = 0.0;
-        if (slot < g.values_size)
+        if (g.mask)
+        {
+            // a real constant on the masked slots: its conjugate has imaginary part -0.0 like std::conj(double)
+            if (slot < g.values_size)
+            {
+                r = g.mask[slot] == 1 ? vals[0] : 0.0;
+                i = s >= slots ? -0.0 : 0.0;
+            }
+        }
+        else if (slot < g.values_size)
         {
             r = g.is_complex ? vals[2 * slot] : vals[slot];
             i = g.is_complex ? vals[2 * slot + 1] : 0.0;
@@ -461,9 +471,9 @@ extern "C" int moai_ckks_tables(moai_ctx *c, uint32_t *index_map, double *inv_ro
     return MOAI_OK;
 }
 
-extern "C" int moai_ckks_encode(moai_ctx *c, const double *values, int is_complex, size_t values_size,
-                                size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index, double scale,
-                                double *max_coeff, void *stream)
+static int encode_impl(moai_ctx *c, const double *values, const int32_t *mask, int is_complex, size_t values_size,
+                       size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index, double scale,
+                       double *max_coeff, void *stream)
 {
     if (!c)
     {
@@ -528,6 +538,7 @@ extern "C" int moai_ckks_encode(moai_ctx *c, const double *values, int is_comple
     }
     EncArgs g;
     g.values = values;
+    g.mask = mask;
     g.src_map = c->ckks_src_map;
     g.roots = reinterpret_cast<const double2 *>(c->ckks_inv_roots);
     g.scratch = static_cast<double2 *>(scratch);
@@ -558,4 +569,22 @@ extern "C" int moai_ckks_encode(moai_ctx *c, const double *values, int is_comple
     MOAI_LAUNCH_CHECK();
     // ckks.h:631-634: ntt_negacyclic_harvey on every row
     return ntt_launch(c, dst, n_batch, L, rows, false, s);
+}
+
+extern "C" int moai_ckks_encode(moai_ctx *c, const double *values, int is_complex, size_t values_size,
+                                size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index, double scale,
+                                double *max_coeff, void *stream)
+{
+    return encode_impl(c, values, nullptr, is_complex, values_size, n_batch, dst, L, prime_index, scale, max_coeff, stream);
+}
+
+extern "C" int moai_ckks_encode_masked(moai_ctx *c, const double *constants, const int32_t *mask, size_t mask_size,
+                                       size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index,
+                                       double scale, double *max_coeff, void *stream)
+{
+    if (!mask && mask_size > 0)
+    {
+        return set_error(MOAI_EINVAL, "mask cannot be null");
+    }
+    return encode_impl(c, constants, mask, 0, mask_size, n_batch, dst, L, prime_index, scale, max_coeff, stream);
 }

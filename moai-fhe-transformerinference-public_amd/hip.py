@@ -59,6 +59,7 @@ SYMBOLS = {
     "moai_apply_galois": (C.c_int, [vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_modraise": (C.c_int, [vp, vp, vp, sz, sz, vp]),
     "moai_ckks_encode": (C.c_int, [vp, vp, C.c_int, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
+    "moai_ckks_encode_masked": (C.c_int, [vp, vp, vp, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
     "moai_total_coeff_modulus_bit_count": (C.c_int, [vp, sz, C.POINTER(C.c_uint32)]),
     "moai_ckks_tables": (C.c_int, [vp, vp, vp]),
     "moai_set_tuning": (C.c_int, [C.c_char_p, C.c_long]),

@@ -67,10 +67,17 @@ namespace moai_fused
 
     inline std::vector<seal::Ciphertext> ct_pt_matrix_mul_wo_pre(const std::vector<seal::Ciphertext> &enc_X,
                                                                  const std::vector<std::vector<double>> &W, int col_X,
-                                                                 int col_W, int row_W, const seal::SEALContext &seal_context)
+                                                                 int col_W, int row_W, const seal::SEALContext &seal_context,
+                                                                 int computed_cols = -1)
     {
         using namespace seal;
         std::vector<Ciphertext> output(static_cast<std::size_t>(col_W));
+        // the "_large" variant of the reference fills only the first 128 * (col_W / 128) columns
+        col_W = computed_cols >= 0 ? computed_cols : col_W;
+        if (col_W == 0)
+        {
+            return output;
+        }
         if (col_X != row_W)
         {
             std::cout << "ERROR: bad dimensions of X or W. " << std::endl;
@@ -128,6 +135,140 @@ namespace moai_fused
         seal_context.sync(); // w and the staging buffers go out of scope
         return output;
     }
+    // include/source/matrix_mul/Ct_pt_matrix_mul.hpp:51-101: the same product with another OpenMP blocking; like
+    // the reference it fills the first 128 * (col_W / 128) output columns
+    inline std::vector<seal::Ciphertext> ct_pt_matrix_mul_wo_pre_large(const std::vector<seal::Ciphertext> &enc_X,
+                                                                       const std::vector<std::vector<double>> &W, int col_X,
+                                                                       int col_W, int row_W,
+                                                                       const seal::SEALContext &seal_context)
+    {
+        return ct_pt_matrix_mul_wo_pre(enc_X, W, col_X, col_W, row_W, seal_context, 128 * (col_W / 128));
+    }
+
+    // moai_fused::ct_pt_matrix_mul_wo_pre_w_mask replaces include/source/matrix_mul/Ct_pt_matrix_mul.hpp:103-170
+    // (self-output and final feed-forward products of the 12-layer run, test_full_scheme.hpp:601,928): every
+    // weight is encoded as the VECTOR mask * w -- rows*cols FP64 transforms, which cannot be shared because
+    // rounding does not commute with the scaling by w.  Here a column's `rows` plaintexts are produced by one
+    // moai_ckks_encode_masked call straight from the weights (nothing but `rows` doubles crosses PCIe), the
+    // products and sums of the column are moai_ct_pt_dot passes, and all columns are rescaled in one call.
+    // Same ciphertexts bit for bit; like the reference only the first 128 * (col_W / 128) columns are computed.
+    inline std::vector<seal::Ciphertext> ct_pt_matrix_mul_wo_pre_w_mask(const std::vector<seal::Ciphertext> &enc_X,
+                                                                        const std::vector<std::vector<double>> &W,
+                                                                        const std::vector<int> &bias_vec, int col_X,
+                                                                        int col_W, int row_W,
+                                                                        const seal::SEALContext &seal_context)
+    {
+        using namespace seal;
+        std::vector<Ciphertext> output(static_cast<std::size_t>(col_W));
+        if (col_X != row_W)
+        {
+            std::cout << "ERROR: bad dimensions of X or W. " << std::endl;
+            return output;
+        }
+        const double scale = enc_X[0].scale();
+        const parms_id_type pid = enc_X[0].parms_id();
+        auto cd = seal_context.get_context_data(pid);
+        if (!cd || !cd->next_context_data())
+        {
+            throw std::invalid_argument("end of modulus switching chain reached");
+        }
+        const auto &cm = cd->parms().coeff_modulus();
+        const std::size_t L = cm.size(), n = seal_context.n(), slots = n >> 1;
+        const std::size_t rows = static_cast<std::size_t>(row_W);
+        const std::size_t cols = static_cast<std::size_t>(128 * (col_W / 128));
+        for (std::size_t j = 0; j < rows; j++)
+        {
+            if (enc_X[j].parms_id() != pid || enc_X[j].size() != 2 || !enc_X[j].is_ntt_form())
+            {
+                throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+            }
+            if (enc_X[j].scale() != scale)
+            {
+                throw std::invalid_argument("scale mismatch");
+            }
+        }
+        // CKKSEncoder::encode and multiply_plain checks (ckks.h:493-497, evaluator.cpp:2351-2357)
+        if (scale <= 0 || (static_cast<int>(std::log2(scale)) + 1 >= cd->total_coeff_modulus_bit_count()))
+        {
+            throw std::invalid_argument("scale out of bounds");
+        }
+        if (static_cast<int>(std::log2(scale * scale)) >= cd->total_coeff_modulus_bit_count())
+        {
+            throw std::invalid_argument("scale out of bounds");
+        }
+        if (bias_vec.size() < slots)
+        {
+            throw std::invalid_argument("bias_vec is shorter than the slot count");
+        }
+        if (cols == 0)
+        {
+            return output;
+        }
+        void *st = seal_context.stream();
+        moai_ctx *dev = seal_context.device();
+        const std::size_t ct_words = 2 * L * n;
+        static_assert(sizeof(int) == 4, "bias_vec is uploaded as int32");
+        util::DeviceArray dmask((slots + 1) / 2, st), dconst(rows + rows, st); // constants, then max |coeff| per vector
+        util::hip_check(moai_memcpy_h2d(dmask.get(), bias_vec.data(), slots * 4, st));
+        util::DeviceArray dX(rows * ct_words, st), dP(rows * L * n, st), dacc(cols * ct_words, st), dtmp(ct_words, st);
+        for (std::size_t j = 0; j < rows; j++)
+        {
+            util::hip_check(moai_memcpy_d2d(dX.get() + j * ct_words, enc_X[j].device_data(), ct_words * 8, st));
+        }
+        std::vector<double> wcol(rows), mx(rows);
+        std::vector<std::uint32_t> idx(64);
+        const int total_bits = cd->total_coeff_modulus_bit_count();
+        for (std::size_t c = 0; c < cols; c++)
+        {
+            for (std::size_t j = 0; j < rows; j++)
+            {
+                wcol[j] = W[j][c];
+            }
+            util::hip_check(moai_memcpy_h2d(dconst.get(), wcol.data(), rows * 8, st));
+            double *max_dev = reinterpret_cast<double *>(dconst.get() + rows);
+            util::hip_check(moai_ckks_encode_masked(dev, reinterpret_cast<const double *>(dconst.get()),
+                                                    reinterpret_cast<const std::int32_t *>(dmask.get()), slots, rows, dP.get(), L,
+                                                    nullptr, scale, max_dev, st));
+            std::uint64_t *acc = dacc.get() + c * ct_words;
+            for (std::size_t j0 = 0; j0 < rows; j0 += 64)
+            {
+                const std::size_t cnt = std::min<std::size_t>(64, rows - j0);
+                for (std::size_t t = 0; t < cnt; t++)
+                {
+                    idx[t] = static_cast<std::uint32_t>(j0 + t);
+                }
+                std::uint64_t *dst = j0 == 0 ? acc : dtmp.get();
+                util::hip_check(moai_ct_pt_dot(dev, dX.get(), dP.get(), dst, idx.data(), idx.data(), cnt, 2, L, st));
+                if (j0)
+                {
+                    util::hip_check(moai_add(dev, acc, dtmp.get(), acc, 2, L, st));
+                }
+            }
+            util::hip_check(moai_memcpy_d2h(mx.data(), max_dev, rows * 8, st));
+            seal_context.sync(); // wcol / mx are reused by the next column
+            for (double m : mx)
+            {
+                int bits = static_cast<int>(std::ceil(std::log2(std::max<>(m, 1.0)))) + 1;
+                if (!(bits < total_bits))
+                {
+                    throw std::invalid_argument("encoded values are too large");
+                }
+            }
+        }
+        util::DeviceArray dres(cols * 2 * (L - 1) * n, st);
+        util::hip_check(moai_rescale(dev, dacc.get(), dres.get(), 2, L, cols, st));
+        const parms_id_type next_id = cd->next_context_data()->parms_id();
+        for (std::size_t c = 0; c < cols; c++)
+        {
+            output[c].resize(seal_context, next_id, 2);
+            util::hip_check(moai_memcpy_d2d(output[c].device_data(), dres.get() + c * 2 * (L - 1) * n, 2 * (L - 1) * n * 8, st));
+            output[c].is_ntt_form() = true;
+            output[c].scale() = scale; // Ct_pt_matrix_mul.hpp:160
+        }
+        seal_context.sync();
+        return output;
+    }
+
     namespace detail
     {
         // The key switches Evaluator::rotate_internal (SEAL/evaluator.cpp:2667-2722) performs for `steps`, as

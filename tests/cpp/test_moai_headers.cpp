@@ -111,6 +111,66 @@ int main()
         }
     }
 
+    // ---- ct_pt_matrix_mul_wo_pre_large (the intermediate feed-forward product): fills 128 * (col_W / 128)
+    // columns; 130 columns leave the last two untouched in MOAI's loop and in the replacement alike --------------
+    {
+        const int cols_l = 130;
+        vector<vector<double>> Wl(num_col, vector<double>(cols_l));
+        for (int r = 0; r < num_col; r++)
+            for (int c = 0; c < cols_l; c++)
+                Wl[r][c] = 0.01 * (r + 1) - 0.003 * c;
+        vector<Ciphertext> Yl = ct_pt_matrix_mul_wo_pre_large(enc_X, Wl, num_col, cols_l, num_col, context);
+        vector<Ciphertext> Yfl = moai_fused::ct_pt_matrix_mul_wo_pre_large(enc_X, Wl, num_col, cols_l, num_col, context);
+        CHECK(Yfl.size() == Yl.size());
+        for (int c = 0; c < 128; c++)
+        {
+            CHECK(Yfl[c].parms_id() == Yl[c].parms_id());
+            CHECK(Yfl[c].download() == Yl[c].download());
+        }
+        CHECK(Yl[129].size() == 0 && Yfl[129].size() == 0);
+    }
+
+    // ---- ct_pt_matrix_mul_wo_pre_w_mask: vector-encoded masked weights; the fused replacement encodes them on
+    // the device and must reproduce MOAI's loop bit for bit (the FP64 transform included) --------------------
+    {
+        const int rows_m = 70, cols_m = 128; // the reference computes 128 * (col_W / 128) columns
+        vector<int> bias_vec(slots, 0);
+        for (size_t s = 0; s < slots; s++)
+            bias_vec[s] = (s % 8 < 5) ? 1 : 0;
+        vector<vector<double>> Wm(rows_m, vector<double>(cols_m));
+        for (int r = 0; r < rows_m; r++)
+            for (int c = 0; c < cols_m; c++)
+                Wm[r][c] = 0.02 * sin(0.7 * r + 0.3 * c) + 1e-3 * r;
+        vector<Ciphertext> Xm(rows_m);
+        for (int r = 0; r < rows_m; r++)
+            Xm[r] = enc_X[r % num_col];
+        vector<Ciphertext> Ym = ct_pt_matrix_mul_wo_pre_w_mask(Xm, Wm, bias_vec, rows_m, cols_m, rows_m, context);
+        vector<Ciphertext> Yf = moai_fused::ct_pt_matrix_mul_wo_pre_w_mask(Xm, Wm, bias_vec, rows_m, cols_m, rows_m, context);
+        CHECK(Yf.size() == Ym.size());
+        for (int c = 0; c < cols_m; c++)
+        {
+            CHECK(Yf[c].parms_id() == Ym[c].parms_id());
+            CHECK(Yf[c].scale() == Ym[c].scale());
+            CHECK(Yf[c].download() == Ym[c].download());
+        }
+        // meaning: column c = mask * sum_r X[r] * W[r][c]
+        Plaintext p;
+        vector<double> out;
+        decryptor.decrypt(Yf[5], p);
+        encoder.decode(p, out);
+        double err = 0;
+        for (int j = 0; j < num_X; j++)
+            for (int k = 0; k < num_row; k++)
+            {
+                double e = 0;
+                for (int r = 0; r < rows_m; r++)
+                    e += X[j][k][r % num_col] * Wm[r][5];
+                size_t slot = (size_t)num_X * k + j;
+                err = max(err, fabs(out[slot] - (bias_vec[slot] == 1 ? e : 0.0)));
+            }
+        CHECK(err < 1e-4);
+    }
+
     // ---- ct_ct_matrix_mul_colpacking ------------------------------------------------------------------
     {
         const int cols = 3, rows = 4, num_batch = num_X;

@@ -225,6 +225,41 @@ int main(int argc, char **argv)
     double t_sv = now_s() - t0;
     printf("softmax(QK^T) V (diagpacking, chain index %zu): %8.3f s\n", context.get_context_data(V[0].parms_id())->chain_index(), t_sv);
 
+    // ---- self-output product (test_full_scheme.hpp:601): 768 x 768 with vector-encoded masked weights, on the
+    // concatenated head outputs (chain index of the .V result) ---------------------------------------------------
+    {
+        vector<Ciphertext> att_output(num_col);
+        for (int i = 0; i < num_col; i++) att_output[i] = out[i % col_W];
+        vector<int> b_vec(slots, 0);
+        for (size_t s = 0; s < slots; s++) b_vec[s] = (s % 128) < 100 ? 1 : 0;
+        vector<vector<double>> Wso(num_col, vector<double>(num_col));
+        for (auto &r : Wso)
+            for (auto &x : r) x = wd(rng);
+        // MOAI's loop on the first 128 of the 768 columns (a sixth of the work), then the fused product on all
+        vector<vector<double>> W128(num_col, vector<double>(128));
+        for (int r = 0; r < num_col; r++)
+            for (int c = 0; c < 128; c++) W128[r][c] = Wso[r][c];
+        context.sync();
+        t0 = now_s();
+        vector<Ciphertext> so_ref = ct_pt_matrix_mul_wo_pre_w_mask(att_output, W128, b_vec, num_col, 128, num_col, context);
+        context.sync();
+        double t_ref = now_s() - t0;
+        vector<Ciphertext> so;
+        double t_f = 0;
+        for (int rep = 0; rep < 2; rep++)
+        {
+            t0 = now_s();
+            so = moai_fused::ct_pt_matrix_mul_wo_pre_w_mask(att_output, Wso, b_vec, num_col, num_col, num_col, context);
+            context.sync();
+            t_f = now_s() - t0;
+        }
+        bool same = true;
+        for (int c : { 0, 17, 127 }) same = same && (so[c].download() == so_ref[c].download());
+        printf("self-output X W (768 x 768, masked vector weights, chain index %zu): MOAI's loop %.2f s for 128 columns (= %.1f s for 768), fused %.3f s for all 768 (%s)\n",
+               context.get_context_data(att_output[0].parms_id())->chain_index(), t_ref, t_ref * 6, t_f,
+               same ? "bit-identical" : "DIFFERENT");
+    }
+
     // ---- GELU on one intermediate ciphertext (gelu_others.hpp gelu_v2; 3072 of these per layer) --------
     t0 = now_s();
     const int gelu_n = 16;

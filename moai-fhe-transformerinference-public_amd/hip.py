@@ -296,6 +296,25 @@ class Context:
             raise MoaiError(MOAI_EINVAL, "encoded values are too large")
         return out, mx
 
+    def ckks_encode_masked(self, constants, mask, L, scale, prime_index=None, stream=None):
+        """moai_ckks_encode_masked: vector b = constants[b] on the slots where mask == 1, 0 elsewhere."""
+        cst = np.ascontiguousarray(constants, dtype=np.float64)
+        msk = np.ascontiguousarray(mask, dtype=np.int32)
+        n_batch = cst.size
+        dc = DeviceBuffer(2 * n_batch + 1)
+        dm = DeviceBuffer((msk.size + 1) // 2 + 1)
+        _check(lib().moai_memcpy_h2d(dc.ptr, cst.ctypes.data, n_batch * 8, stream))
+        _check(lib().moai_memcpy_h2d(dm.ptr, msk.ctypes.data, msk.size * 4, stream))
+        out = DeviceBuffer(n_batch * L * self.n)
+        mx_ptr = dc.ptr + n_batch * 8
+        _check(lib().moai_ckks_encode_masked(self.h, dc.ptr, dm.ptr, msk.size, n_batch, out.ptr, L,
+                                             self._pidx(prime_index), float(scale), mx_ptr, stream))
+        mx = np.empty(n_batch, dtype=np.float64)
+        _check(lib().moai_stream_sync(stream))
+        _check(lib().moai_memcpy_d2h(mx.ctypes.data, mx_ptr, n_batch * 8, stream))
+        _check(lib().moai_stream_sync(stream))
+        return out, mx
+
     def total_coeff_modulus_bit_count(self, L, prime_index=None):
         r = lib().moai_total_coeff_modulus_bit_count(self.h, L, self._pidx(prime_index))
         if r == 0:

@@ -104,3 +104,28 @@ def test_encode_errors(moai):
         ctx.ckks_encode(np.full(32, 1e12), 2, 2.0**30)
     out, mx = ctx.ckks_encode(np.zeros((0, 4)), 2, 2.0**20)  # empty batch
     assert mx.size == 0
+
+
+@pytest.mark.parametrize("logn,bits", [(6, [40, 40]), (12, [51, 46, 58]), (16, [51, 46, 46])])
+def test_encode_masked_constants(moai, logn, bits):
+    # the vectors MOAI's masked matrix product encodes (Ct_pt_matrix_mul.hpp:124-146): w on the slots with
+    # bias_vec == 1, zero elsewhere; other mask values (0, 2, -1) count as "not 1" like the reference's test
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    enc = O.CkksEncoder(octx)
+    rng = np.random.default_rng(logn)
+    slots = n // 2
+    mask = rng.integers(-1, 3, size=slots).astype(np.int32)
+    w = np.concatenate([rng.normal(scale=0.02, size=5), [0.0, -0.0, 1.0]])
+    L = len(primes) - 1
+    out, mx = ctx.ckks_encode_masked(w, mask, L, 2.0**30)
+    got = out.to_numpy((w.size, L, n))
+    for b in range(w.size):
+        assert (got[b] == enc.encode(np.where(mask == 1, w[b], 0.0), L, 2.0**30)).all()
+    # a shorter mask leaves the remaining slots zero
+    out, _ = ctx.ckks_encode_masked(w[:2], mask[: slots // 2], L, 2.0**30)
+    got = out.to_numpy((2, L, n))
+    v = np.zeros(slots)
+    v[: slots // 2] = np.where(mask[: slots // 2] == 1, w[1], 0.0)
+    assert (got[1] == enc.encode(v, L, 2.0**30)).all()

@@ -79,6 +79,9 @@ struct moai_ctx
     // fwd_twb; rows of primes that have no FP64 mode are zero
     moai::Tw *fwd_twf = nullptr;
     moai::Tw *fwd_twfb = nullptr;
+    // the same powers as plain doubles, 8 bytes per entry (fwd_tw indexing): the contiguous key-switch kernel is
+    // bound by twiddle fetches and takes its quotient estimate from RN(1/q) instead (modarith.cuh ct_bfly_fp1)
+    double *fwd_twf1 = nullptr;
     moai::PrimeConst *pc = nullptr;    // [k]
     // inv_q_last_mod_q[l][i] = q_l^-1 mod q_i as Shoup operands, l in [1,k), i < l  (rns.cpp:769-775)
     moai::Tw *inv_qlast = nullptr;     // [k][k]

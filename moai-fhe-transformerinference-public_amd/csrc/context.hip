@@ -198,13 +198,13 @@ static void build_prime(int logn, uint64_t q, uint64_t psi, Tw *fwd, Tw *inv, Pr
         pc->cr1 = q1;
     }
     // FP64 arithmetic modes (modarith.cuh): q < 2^51; without intermediate reductions when sixteen stages
-    // starting from |x| <= q/2 and growing by at most 1.5 q each stay below 2^52
+    // starting from |x| <= q/2 and growing by at most 2 q each (the w-only butterfly, ct_bfly_fp1) stay below 2^52
     if (q < (1ull << 51))
     {
         const double qd = (double)q, qinv = 1.0 / (double)q;
         memcpy(&pc->qd, &qd, 8);
         memcpy(&pc->qinv, &qinv, 8);
-        pc->fp_mode = (25 * (unsigned __int128)q < ((unsigned __int128)1 << 52)) ? 2 : 3; // M_FPN : M_FPR
+        pc->fp_mode = (33 * (unsigned __int128)q < ((unsigned __int128)1 << 52)) ? 2 : 3; // M_FPN : M_FPR
     }
     uint64_t ninv = powmod((uint64_t)n % q, q - 2, q);
     pc->ninv = make_tw(ninv, q);
@@ -361,8 +361,10 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
     }
     // FP64 forward tables: {double w, double RN(w / q)} in the two words of a Tw (modarith.cuh)
     std::vector<Tw> fwdf, fwdfb;
+    std::vector<double> fwdf1;
     if (logn >= 12)
     {
+        fwdf1.assign(k * n, 0.0);
         fwdf.assign(k * n, Tw{ 0, 0 });
         fwdfb.assign(k * nb, Tw{ 0, 0 });
         auto to_fp = [](Tw t, uint64_t q) {
@@ -381,6 +383,7 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
             for (size_t i = 0; i < n; i++)
             {
                 fwdf[p * n + i] = to_fp(fwd[p * n + i], primes[p]);
+                fwdf1[p * n + i] = (double)fwd[p * n + i].w;
             }
             for (size_t i = 0; i < nb; i++)
             {
@@ -407,6 +410,8 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         (e = hipMalloc(&c->inv_tw, sizeof(Tw) * k * n)) != hipSuccess ||
         (e = hipMalloc(&c->pc, sizeof(PrimeConst) * k)) != hipSuccess ||
         (e = hipMalloc(&c->inv_qlast, sizeof(Tw) * k * k)) != hipSuccess ||
+        (nb && (e = hipMalloc(&c->fwd_twf1, sizeof(double) * k * n)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->fwd_twf1, fwdf1.data(), sizeof(double) * k * n, hipMemcpyHostToDevice)) != hipSuccess) ||
         (nb && (e = hipMalloc(&c->fwd_twf, sizeof(Tw) * k * n)) != hipSuccess) ||
         (nb && (e = hipMalloc(&c->fwd_twfb, sizeof(Tw) * k * nb)) != hipSuccess) ||
         (nb && (e = hipMemcpy(c->fwd_twf, fwdf.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess) ||
@@ -440,6 +445,7 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
     (void)hipFree(c->pc);
     (void)hipFree(c->inv_qlast);
     (void)hipFree(c->fwd_twf);
+    (void)hipFree(c->fwd_twf1);
     (void)hipFree(c->fwd_twfb);
     (void)hipFree(c->fwd_twb);
     (void)hipFree(c->inv_twb);

@@ -497,6 +497,7 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.key = key;
     p2.acc = acc;
     p2.tw = MODE >= M_FPN ? c->fwd_twf : c->fwd_tw;
+    p2.tw1 = c->fwd_twf1;
     p2.pc = c->pc;
     p2.grp = grp;
     p2.L = (uint32_t)L;

@@ -96,6 +96,7 @@ struct KsP2Args
     const uint64_t *key; // [k-1][2][k][N]
     uint64_t *acc;       // [B][2][L+1][N]
     const Tw *tw;
+    const double *tw1;   // FP64 modes: the forward powers as plain doubles
     const PrimeConst *pc;
     KsGroup grp;
     uint32_t L;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
     const uint64_t q = pc->q;
     const uint64_t bq1 = mode_q<MODE>(*pc), bq2 = mode_q2<MODE>(*pc); // the butterflies' (q, q2) under MODE
     const Tw *__restrict__ tw = a.tw + ((size_t)prime << LOGN);
+    const double *__restrict__ tw1 = a.tw1 + ((size_t)prime << LOGN);
     const uint32_t tid0 = threadIdx.x;
 
     uint64_t lo0[8], hi0[8], lo1[8], hi1[8];
@@ -200,8 +202,15 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             {
                 if (!(j & half))
                 {
-                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))];
-                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
+                    if (MODE >= M_FPN)
+                    {
+                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))], u2d(bq1), u2d(bq2));
+                    }
+                    else
+                    {
+                        Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))];
+                        ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
+                    }
                 }
             }
         }
@@ -226,8 +235,15 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 if (!(j & half))
                 {
                     uint32_t t_ = (hi3 << 5) | ((uint32_t)j << 2) | lo2;
-                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
-                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
+                    if (MODE >= M_FPN)
+                    {
+                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))], u2d(bq1), u2d(bq2));
+                    }
+                    else
+                    {
+                        Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
+                        ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
+                    }
                 }
             }
         }
@@ -255,8 +271,15 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 if (!(j & half))
                 {
                     uint32_t t_ = (r << 3) | (uint32_t)j;
-                    Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
-                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
+                    if (MODE >= M_FPN)
+                    {
+                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))], u2d(bq1), u2d(bq2));
+                    }
+                    else
+                    {
+                        Tw t = tw[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))];
+                        ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, bq1, bq2);
+                    }
                 }
             }
         }

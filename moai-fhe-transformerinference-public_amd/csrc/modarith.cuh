@@ -168,6 +168,24 @@ __device__ __forceinline__ void ct_bfly_fp(uint64_t &xb, uint64_t &yb, uint64_t 
     yb = d2u(u - v);
 }
 
+// The same butterfly with the twiddle given as w alone (8 bytes instead of 16): the quotient is estimated from
+// RN(y w) * RN(1/q) like fp_mulmod_q.  The estimate is off by up to 3 * 2^-53 |y|, so the product comes out with
+// |v| < 2q for |y| < 2^52: sixteen stages from q/2 stay below 33 q (M_FPN needs 33 q < 2^52, true for primes
+// below 2^46.9); M_FPR reduces BOTH operands first, which keeps |v| < 0.9 q.
+template <bool RED>
+__device__ __forceinline__ void ct_bfly_fp1(uint64_t &xb, uint64_t &yb, double w, double q, double qinv)
+{
+    double u = u2d(xb), y = u2d(yb);
+    if (RED)
+    {
+        u = fp_red(u, q, qinv);
+        y = fp_red(y, q, qinv);
+    }
+    double v = fp_mulmod_q(y, w, q, qinv);
+    xb = d2u(u + v);
+    yb = d2u(u - v);
+}
+
 template <int MODE>
 __device__ __forceinline__ void ct_bfly_t(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {

@@ -100,37 +100,48 @@ namespace moai_fused
                 throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
             }
         }
-        // the scalar plaintexts' residues, exactly as CKKSEncoder::encode(double, parms_id, scale) makes them
+        // the scalar plaintexts' residues, exactly as CKKSEncoder::encode(double, parms_id, scale) makes them;
+        // output columns in chunks, so that the staging buffers stay within a few GiB however wide W is
         CKKSEncoder encoder(seal_context);
-        std::vector<std::uint64_t> w(L * rows * cols);
+        void *st = seal_context.stream();
+        const std::size_t ct_words = 2 * L * n;
+        const std::size_t chunk = std::max<std::size_t>(16, std::min<std::size_t>(cols, (std::size_t(4) << 30) / (ct_words * 8)));
+        util::DeviceArray dx(rows * ct_words, st), dw(L * rows * chunk, st), dout(chunk * ct_words, st),
+            dres(chunk * 2 * (L - 1) * n, st);
         for (std::size_t j = 0; j < rows; j++)
         {
-            for (std::size_t c = 0; c < cols; c++)
+            util::hip_check(moai_memcpy_d2d(dx.get() + j * ct_words, enc_X[j].device_data(), ct_words * 8, st));
+        }
+        const parms_id_type next_id = cd->next_context_data()->parms_id();
+        std::vector<std::uint64_t> w;
+        for (std::size_t c0 = 0; c0 < cols; c0 += chunk)
+        {
+            const std::size_t cc = std::min(chunk, cols - c0);
+            w.assign(L * rows * cc, 0);
+            for (std::size_t j = 0; j < rows; j++)
             {
-                Plaintext p;
-                encoder.encode(W[j][c], pid, enc_X[j].scale(), p);
-                for (std::size_t r = 0; r < L; r++)
+                for (std::size_t c = 0; c < cc; c++)
                 {
-                    w[(r * rows + j) * cols + c] = p.scalar_rows()[r];
+                    Plaintext p;
+                    encoder.encode(W[j][c0 + c], pid, enc_X[j].scale(), p);
+                    for (std::size_t r = 0; r < L; r++)
+                    {
+                        w[(r * rows + j) * cc + c] = p.scalar_rows()[r];
+                    }
                 }
             }
-        }
-        void *st = seal_context.stream();
-        util::DeviceArray dw(w.size(), st), dx(rows * 2 * L * n, st), dout(cols * 2 * L * n, st), dres(cols * 2 * (L - 1) * n, st);
-        util::hip_check(moai_memcpy_h2d(dw.get(), w.data(), w.size() * 8, st));
-        for (std::size_t j = 0; j < rows; j++)
-        {
-            util::hip_check(moai_memcpy_d2d(dx.get() + j * 2 * L * n, enc_X[j].device_data(), 2 * L * n * 8, st));
-        }
-        util::hip_check(moai_ct_pt_matmul(seal_context.device(), dx.get(), dw.get(), dout.get(), rows, cols, 2, L, st));
-        util::hip_check(moai_rescale(seal_context.device(), dout.get(), dres.get(), 2, L, cols, st));
-        const parms_id_type next_id = cd->next_context_data()->parms_id();
-        for (std::size_t c = 0; c < cols; c++)
-        {
-            output[c].resize(seal_context, next_id, 2);
-            util::hip_check(moai_memcpy_d2d(output[c].device_data(), dres.get() + c * 2 * (L - 1) * n, 2 * (L - 1) * n * 8, st));
-            output[c].is_ntt_form() = true;
-            output[c].scale() = scale; // Ct_pt_matrix_mul.hpp:41
+            util::hip_check(moai_memcpy_h2d(dw.get(), w.data(), w.size() * 8, st));
+            util::hip_check(moai_ct_pt_matmul(seal_context.device(), dx.get(), dw.get(), dout.get(), rows, cc, 2, L, st));
+            util::hip_check(moai_rescale(seal_context.device(), dout.get(), dres.get(), 2, L, cc, st));
+            for (std::size_t c = 0; c < cc; c++)
+            {
+                Ciphertext &o = output[c0 + c];
+                o.resize(seal_context, next_id, 2);
+                util::hip_check(moai_memcpy_d2d(o.device_data(), dres.get() + c * 2 * (L - 1) * n, 2 * (L - 1) * n * 8, st));
+                o.is_ntt_form() = true;
+                o.scale() = scale; // Ct_pt_matrix_mul.hpp:41
+            }
+            seal_context.sync(); // w is refilled for the next chunk
         }
         seal_context.sync(); // w and the staging buffers go out of scope
         return output;

@@ -251,18 +251,34 @@ namespace seal
                 const std::size_t step = std::size_t(1) << (top - 3);
                 return (bytes + step - 1) & ~(step - 1);
             }
-            void *acquire(std::size_t bytes, void *stream)
+            // *granted (optional) receives the size of the block handed out, which may exceed the request
+            void *acquire(std::size_t bytes, void *stream, std::size_t *granted = nullptr)
             {
                 {
+                    // best fit among this stream's cached blocks, up to 1.5 x the request: a rescale / mod-switch
+                    // chain asks for slightly smaller blocks at every step and would otherwise grow a free list
+                    // per level
                     std::lock_guard<std::mutex> g(mu_);
-                    auto it = free_.find({ stream, bytes });
-                    if (it != free_.end() && !it->second.empty())
+                    auto it = free_.lower_bound({ stream, bytes });
+                    while (it != free_.end() && it->first.first == stream && it->first.second <= bytes + bytes / 2)
                     {
-                        void *p = it->second.back();
-                        it->second.pop_back();
-                        cached_ -= bytes;
-                        return p;
+                        if (!it->second.empty())
+                        {
+                            void *p = it->second.back();
+                            it->second.pop_back();
+                            cached_ -= it->first.second;
+                            if (granted)
+                            {
+                                *granted = it->first.second;
+                            }
+                            return p;
+                        }
+                        ++it;
                     }
+                }
+                if (granted)
+                {
+                    *granted = bytes;
                 }
                 void *p = nullptr;
                 int rc = moai_malloc(&p, bytes);
@@ -368,8 +384,10 @@ namespace seal
                     words_ = words;
                     return;
                 }
-                const std::size_t alloc_words = DevicePool::size_class(words * sizeof(std::uint64_t)) / sizeof(std::uint64_t);
-                void *p = DevicePool::instance().acquire(alloc_words * sizeof(std::uint64_t), stream);
+                std::size_t alloc_words = DevicePool::size_class(words * sizeof(std::uint64_t)) / sizeof(std::uint64_t);
+                std::size_t granted = 0;
+                void *p = DevicePool::instance().acquire(alloc_words * sizeof(std::uint64_t), stream, &granted);
+                alloc_words = granted / sizeof(std::uint64_t);
                 if (ptr_ && words_)
                 {
                     // ordered on `stream`; the old block goes back to the pool of its own stream and can only

@@ -68,6 +68,9 @@ uint64_t moai_ctx_root(const moai_ctx *ctx, size_t prime);
 
 /* ---- memory / streams (the device arena behind seal::DynArray / MemoryPool, SEAL/dynarray.h) -- */
 int moai_malloc(void **dptr, size_t bytes);
+/* page-locked host memory: copies from it are asynchronous for real (staging buffers of host-side callers) */
+int moai_host_malloc(void **hptr, size_t bytes);
+int moai_host_free(void *hptr);
 int moai_free(void *dptr);
 int moai_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
 int moai_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
@@ -253,6 +256,7 @@ int moai_device_info(int device, char *name, size_t name_cap, int *compute_units
 int moai_event_create(void **event);
 int moai_event_destroy(void *event);
 int moai_event_record(void *event, void *stream);
+int moai_event_synchronize(void *event);
 int moai_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 #ifdef __cplusplus

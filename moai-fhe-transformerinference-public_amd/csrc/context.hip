@@ -630,6 +630,35 @@ extern "C" int moai_event_destroy(void *ev)
     return MOAI_OK;
 }
 
+extern "C" int moai_event_synchronize(void *ev)
+{
+    MOAI_HIP_CHECK(hipEventSynchronize((hipEvent_t)ev));
+    return MOAI_OK;
+}
+
+extern "C" int moai_host_malloc(void **hptr, size_t bytes)
+{
+    if (!hptr)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 8, hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+        return set_error(MOAI_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return MOAI_OK;
+}
+
+extern "C" int moai_host_free(void *hptr)
+{
+    if (hptr)
+    {
+        MOAI_HIP_CHECK(hipHostFree(hptr));
+    }
+    return MOAI_OK;
+}
+
 extern "C" int moai_event_record(void *ev, void *stream)
 {
     MOAI_HIP_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));

@@ -67,6 +67,9 @@ SYMBOLS = {
     "moai_event_create": (C.c_int, [C.POINTER(vp)]),
     "moai_event_destroy": (C.c_int, [vp]),
     "moai_event_record": (C.c_int, [vp, vp]),
+    "moai_event_synchronize": (C.c_int, [vp]),
+    "moai_host_malloc": (C.c_int, [C.POINTER(vp), sz]),
+    "moai_host_free": (C.c_int, [vp]),
     "moai_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
 }
 

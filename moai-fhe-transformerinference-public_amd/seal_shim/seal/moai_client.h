@@ -3,6 +3,7 @@
 //  but needed so that MOAI's programs link and run.  Their NTTs are
 // executed on the device through moai_ntt_forward / moai_ntt_inverse.
 #pragma once
+#include <cstring>
 
 namespace seal
 {
@@ -308,10 +309,26 @@ namespace seal
             const std::size_t L = cm.size();
             const std::size_t words = count * (is_complex ? 2 : 1);
             void *stream = context_.stream();
+            // Every coefficient is (scale / N) * sum of N unit-modulus multiples of the slot values and their
+            // conjugates, so |coefficient| <= scale * max |value|.  When that bound already passes the
+            // reference's range check (ckks.h:527-538) the check cannot fail and nothing has to come back from
+            // the device; otherwise the exact maximum is fetched and tested like the reference does.
+            double max_abs = 0;
+            for (std::size_t i = 0; i < count; i++)
+            {
+                max_abs = std::max<>(max_abs, static_cast<double>(std::abs(values[i])));
+            }
+            const double bound = scale * max_abs * (1.0 + 1e-9);
+            const bool conclusive = std::isfinite(bound) && static_cast<int>(std::ceil(std::log2(std::max<>(bound, 1.0)))) + 1 <
+                                                                cd->total_coeff_modulus_bit_count();
             util::DeviceArray staging(words + 1, stream); // values, then max |coefficient|
+            StagingSlot &slot = staging_slot(words * 8);
             if (words)
             {
-                util::hip_check(moai_memcpy_h2d(staging.get(), as_doubles(values), words * 8, stream));
+                // through page-locked memory, so that the copy is asynchronous and the caller's vector is free
+                // again when this function returns
+                std::memcpy(slot.host, as_doubles(values), words * 8);
+                util::hip_check(moai_memcpy_h2d(staging.get(), slot.host, words * 8, stream));
             }
             destination.scalar_rows_.clear();
             destination.parms_id_ = parms_id_zero;
@@ -322,19 +339,59 @@ namespace seal
             double *max_dev = reinterpret_cast<double *>(staging.get() + words);
             util::hip_check(moai_ckks_encode(context_.device(), reinterpret_cast<const double *>(staging.get()),
                                              is_complex ? 1 : 0, count, 1, destination.data_.get(), L, nullptr, scale,
-                                             max_dev, stream));
-            double max_coeff = 0;
-            util::hip_check(moai_memcpy_d2h(&max_coeff, max_dev, 8, stream));
-            context_.sync();
-            // ckks.h:527-538 (the negated comparison also catches NaN)
-            int max_coeff_bit_count = static_cast<int>(std::ceil(std::log2(std::max<>(max_coeff, 1.0)))) + 1;
-            if (!(max_coeff_bit_count < cd->total_coeff_modulus_bit_count()))
+                                             conclusive ? nullptr : max_dev, stream));
+            util::hip_check(moai_event_record(slot.event, stream));
+            slot.pending = true;
+            if (!conclusive)
             {
-                destination.data_.release();
-                throw std::invalid_argument("encoded values are too large");
+                double max_coeff = 0;
+                util::hip_check(moai_memcpy_d2h(&max_coeff, max_dev, 8, stream));
+                context_.sync();
+                // ckks.h:527-538 (the negated comparison also catches NaN)
+                int max_coeff_bit_count = static_cast<int>(std::ceil(std::log2(std::max<>(max_coeff, 1.0)))) + 1;
+                if (!(max_coeff_bit_count < cd->total_coeff_modulus_bit_count()))
+                {
+                    destination.data_.release();
+                    throw std::invalid_argument("encoded values are too large");
+                }
             }
             destination.parms_id_ = parms_id;
             destination.scale_ = scale;
+        }
+
+        // page-locked staging buffers for the values of vector encodes: a small ring per host thread; a slot is
+        // reused only after the event recorded behind its last copy has completed
+        struct StagingSlot
+        {
+            void *host = nullptr;
+            std::size_t bytes = 0;
+            void *event = nullptr;
+            bool pending = false;
+        };
+        static StagingSlot &staging_slot(std::size_t bytes)
+        {
+            static thread_local StagingSlot ring[4];
+            static thread_local unsigned next = 0;
+            StagingSlot &s = ring[next++ & 3u];
+            if (s.pending)
+            {
+                util::hip_check(moai_event_synchronize(s.event));
+                s.pending = false;
+            }
+            if (!s.event)
+            {
+                util::hip_check(moai_event_create(&s.event));
+            }
+            if (s.bytes < bytes)
+            {
+                if (s.host)
+                {
+                    util::hip_check(moai_host_free(s.host));
+                }
+                s.bytes = std::max<std::size_t>(bytes, std::size_t(1) << 16);
+                util::hip_check(moai_host_malloc(&s.host, s.bytes));
+            }
+            return s;
         }
 
         void encode_scalar(double value, parms_id_type parms_id, double scale, Plaintext &destination) const

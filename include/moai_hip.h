@@ -244,7 +244,7 @@ int moai_ckks_tables(moai_ctx *ctx, uint32_t *index_map, double *inv_root_powers
 /* ---- tuning -------------------------------------------------------------------------------------------------------
  * Overrides a performance knob for the whole process (same names as the environment variables read by the
  * library, which it takes precedence over).  Results never depend on these.  Currently:
- *   MOAI_KS_FP_MIN_ROWS  batch * L from which the key switch uses the FP64 arithmetic modes (default 256) */
+ *   MOAI_KS_FP_MIN_ROWS  batch * L from which the key switch uses the FP64 arithmetic modes (default 16) */
 int moai_set_tuning(const char *name, long value);
 
 /* ---- measurement support -----------------------------------------------------------------------------------

@@ -581,8 +581,8 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         // output moduli (I = L stands for the special prime) ordered by arithmetic mode; a launch covers up to
         // G of them, all of one mode
         // every mode is one more pair of launches: a few ciphertexts at a low level are launch-bound and stay
-        // on the single integer group (measured: FP64 pays from about 256 digit rows per call)
-        const bool allow_fp = (long)(batch * L) >= tuning("MOAI_KS_FP_MIN_ROWS", 256);
+        // on the single integer group (measured: FP64 pays from about 16 digit rows per call)
+        const bool allow_fp = (long)(batch * L) >= tuning("MOAI_KS_FP_MIN_ROWS", 16);
         std::vector<uint16_t> order;
         std::vector<int> order_mode;
         for (int mode = M_FPR; mode >= M_GUARD; --mode)

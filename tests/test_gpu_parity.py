@@ -19,10 +19,10 @@ def up(m, a):
 @pytest.fixture(params=["fp64", "int64"])
 def ks_arith(request, moai):
     """Key-switch tests run twice: with the FP64 arithmetic modes forced on for every prime below 2^51 (the
-    library only picks them from 256 digit rows per call) and with the integer units only."""
+    library only picks them from 16 digit rows per call) and with the integer units only."""
     moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 0 if request.param == "fp64" else 1 << 40)
     yield request.param
-    moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 256)
+    moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 16)
 
 
 @pytest.fixture(scope="module")

@@ -218,8 +218,35 @@ namespace seal
             const std::size_t L = encrypted.coeff_modulus_size();
             Ciphertext out;
             out.resize_batch(context_, encrypted.parms_id(), 2, encrypted.batch());
-            hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0), out.device_data(), L,
-                                 encrypted.batch(), st()));
+            util::OpCombiner &comb = util::OpCombiner::instance();
+            if (encrypted.batch() == 1 && comb.enabled())
+            {
+                const std::uint64_t *key = relin_keys.device_key(0);
+                const std::size_t rn = L * encrypted.poly_modulus_degree();
+                comb.submit(util::OpCombiner::Key(1, L, 0, key, dev()), { encrypted.device_data(), out.device_data() },
+                            [&](const std::vector<util::OpCombiner::Request> &reqs) {
+                                if (reqs.size() == 1)
+                                {
+                                    hip(moai_relinearize(dev(), reqs[0].in, key, reqs[0].out, L, 1, st()));
+                                    return;
+                                }
+                                util::DeviceArray tin(reqs.size() * 3 * rn, st()), tout(reqs.size() * 2 * rn, st());
+                                for (std::size_t i = 0; i < reqs.size(); i++)
+                                {
+                                    hip(moai_memcpy_d2d(tin.get() + i * 3 * rn, reqs[i].in, 3 * rn * 8, st()));
+                                }
+                                hip(moai_relinearize(dev(), tin.get(), key, tout.get(), L, reqs.size(), st()));
+                                for (std::size_t i = 0; i < reqs.size(); i++)
+                                {
+                                    hip(moai_memcpy_d2d(reqs[i].out, tout.get() + i * 2 * rn, 2 * rn * 8, st()));
+                                }
+                            });
+            }
+            else
+            {
+                hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0), out.device_data(), L,
+                                     encrypted.batch(), st()));
+            }
             out.is_ntt_form() = true;
             out.scale() = encrypted.scale();
             encrypted = std::move(out);
@@ -501,8 +528,34 @@ namespace seal
             {
                 throw std::invalid_argument("CKKS encrypted must be in NTT form");
             }
-            hip(moai_apply_galois(dev(), encrypted.device_data(), encrypted.coeff_modulus_size(), galois_elt,
-                                  galois_keys.device_key(GaloisKeys::get_index(galois_elt)), encrypted.batch(), st()));
+            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt));
+            const std::size_t L = encrypted.coeff_modulus_size();
+            util::OpCombiner &comb = util::OpCombiner::instance();
+            if (encrypted.batch() == 1 && comb.enabled())
+            {
+                // concurrent callers with the same element, level and key share one batched key switch
+                const std::size_t words = 2 * L * encrypted.poly_modulus_degree();
+                comb.submit(util::OpCombiner::Key(0, L, galois_elt, key, dev()), { encrypted.device_data(), encrypted.device_data() },
+                            [&](const std::vector<util::OpCombiner::Request> &reqs) {
+                                if (reqs.size() == 1)
+                                {
+                                    hip(moai_apply_galois(dev(), reqs[0].out, L, galois_elt, key, 1, st()));
+                                    return;
+                                }
+                                util::DeviceArray tmp(reqs.size() * words, st());
+                                for (std::size_t i = 0; i < reqs.size(); i++)
+                                {
+                                    hip(moai_memcpy_d2d(tmp.get() + i * words, reqs[i].in, words * 8, st()));
+                                }
+                                hip(moai_apply_galois(dev(), tmp.get(), L, galois_elt, key, reqs.size(), st()));
+                                for (std::size_t i = 0; i < reqs.size(); i++)
+                                {
+                                    hip(moai_memcpy_d2d(reqs[i].out, tmp.get() + i * words, words * 8, st()));
+                                }
+                            });
+                return;
+            }
+            hip(moai_apply_galois(dev(), encrypted.device_data(), L, galois_elt, key, encrypted.batch(), st()));
         }
         void apply_galois(const Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
                           Ciphertext &destination, MemoryPoolHandle = MemoryPoolHandle()) const

@@ -1196,5 +1196,6 @@ namespace seal
     };
 } // namespace seal
 
+#include "seal/moai_combiner.h"
 #include "seal/moai_client.h"
 #include "seal/moai_evaluator.h"

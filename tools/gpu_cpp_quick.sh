@@ -1,8 +1,6 @@
-set -e
 cd /root/repo
-for t in test_seal_shim test_moai_headers test_bootstrap_lt; do
-  timeout -k 10 300 tests/cpp/$t > gpurun_out/$t.log 2>&1 || { tail -30 gpurun_out/$t.log; exit 1; }
-  tail -1 gpurun_out/$t.log
+for w in 150 500 1500 4000; do
+echo "== window $w us"
+MOAI_SHIM_COMBINE_US=$w timeout -k 10 600 tools/cpp/bench_bootstrap_lt 32 16 2>&1 | tail -2 | head -1
+MOAI_SHIM_COMBINE_US=$w timeout -k 10 900 tools/cpp/bench_attention 16 768 2>&1 | grep "Q K^T (col\|softmax(QK\|gelu_v2 on 16"
 done
-timeout -k 10 600 tools/cpp/bench_bootstrap_lt 32 16 2>&1 | tail -3
-timeout -k 10 900 tools/cpp/bench_attention 16 768 2>&1 | grep "self-output\|bias"

@@ -7,6 +7,8 @@
 
 #include "seal/seal.h"
 
+#include <omp.h>
+
 using namespace seal;
 using namespace std;
 
@@ -333,12 +335,70 @@ static void evaluator_ops()
     }
 }
 
+// Concurrent callers: the shim coalesces key switches that arrive together (seal/moai_combiner.h).  Twelve host
+// threads rotate, square + relinearize and rescale their own ciphertexts at the same time, several rounds; every
+// result must equal the one computed by a single thread.
+static void concurrent_callers()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t n = 4096;
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(CoeffModulus::Create(n, { 51, 46, 46, 46, 58 }));
+    parms.set_secret_key_hamming_weight(64);
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    RelinKeys rk;
+    keygen.create_relin_keys(rk);
+    GaloisKeys gk;
+    keygen.create_galois_keys(gk);
+    CKKSEncoder encoder(context);
+    Encryptor encryptor(context, pk);
+    Evaluator evaluator(context, encoder);
+    const int T = 12;
+    const double scale = pow(2.0, 40);
+    vector<Ciphertext> in(T);
+    for (int t = 0; t < T; t++)
+    {
+        vector<double> v(encoder.slot_count());
+        for (size_t s = 0; s < v.size(); s++) v[s] = 0.01 * t + 1e-4 * (double)(s % 97);
+        Plaintext p;
+        encoder.encode(v, scale, p);
+        encryptor.encrypt(p, in[t]);
+    }
+    auto work = [&](const Ciphertext &x, int t) {
+        Ciphertext a = x;
+        evaluator.rotate_vector_inplace(a, 1, gk);            // same element for everybody
+        evaluator.rotate_vector_inplace(a, 3 + (t % 2), gk);  // NAF path, two different sequences
+        Ciphertext sq;
+        evaluator.square(a, sq);
+        evaluator.relinearize_inplace(sq, rk);
+        evaluator.rescale_to_next_inplace(sq);
+        evaluator.complex_conjugate_inplace(sq, gk);
+        return sq;
+    };
+    vector<vector<uint64_t>> want(T);
+    for (int t = 0; t < T; t++) want[t] = work(in[t], t).download();
+    for (int round = 0; round < 5; round++)
+    {
+        vector<vector<uint64_t>> got(T);
+#pragma omp parallel for num_threads(T)
+        for (int t = 0; t < T; t++)
+        {
+            got[t] = work(in[t], t).download();
+        }
+        for (int t = 0; t < T; t++) CHECK(got[t] == want[t]);
+    }
+}
+
 int main()
 {
     try
     {
         config1();
         evaluator_ops();
+        concurrent_callers();
     }
     catch (const std::exception &e)
     {

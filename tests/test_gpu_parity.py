@@ -528,3 +528,64 @@ def test_key_switch_replays_from_a_hip_graph(moai, ks_arith):
         torch.cuda.synchronize()
         got = ct_static.cpu().numpy().view(np.uint64)
         assert (got == octx.apply_galois(ct, L, elt, key).reshape(2, L, n)).all()
+
+
+def test_fp64_modes_at_their_size_limits(moai):
+    """Primes at the edges of the FP64 arithmetic modes (modarith.cuh): the largest ones below 2^51 (M_FPR), around
+    2^52 / 33 where M_FPN ends, and a 52-bit one that must stay on the integer units; worst-case magnitudes
+    (all residues q - 1, key and digits alike) and random data, forward NTT and key switch against the oracle."""
+    logn = 12
+    n = 1 << logn
+    step = 2 * n
+
+    def prime_below(limit, count):
+        out, v = [], (limit - 1) // step * step + 1
+        while len(out) < count:
+            if O.lib().mo_is_prime(v):
+                out.append(v)
+            v -= step
+        return out
+
+    fpn_limit = (1 << 52) // 33
+    primes = prime_below(1 << 51, 2) + prime_below(fpn_limit, 1) + prime_below(fpn_limit + 40 * step, 1)[:1] \
+        + prime_below(1 << 46, 1) + prime_below(1 << 52, 1) + prime_below(1 << 58, 1)
+    assert len(set(primes)) == len(primes)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k = len(primes)
+    rng = np.random.default_rng(77)
+    moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 0)
+    try:
+        # forward NTT: canonical extremes and lazy inputs up to 4q - 1
+        x = O.uniform_rns(rng, primes, (3,), n)
+        for i, q in enumerate(primes):
+            x[0, i, :] = q - 1
+            x[1, i, ::2] = 0
+            x[1, i, 1::2] = q - 1
+        d = up(moai, x)
+        ctx.ntt_forward(d, 3, k)
+        assert (d.to_numpy(x.shape) == octx.ntt(x, k)).all()
+        lazy = x.copy()
+        for i, q in enumerate(primes):
+            lazy[2, i, :] = (lazy[2, i, :] + np.uint64(3 * q)) if q < (1 << 51) else lazy[2, i, :]
+        d = up(moai, lazy)
+        ctx.ntt_forward(d, 3, k)
+        assert (d.to_numpy(x.shape) == octx.ntt(x, k)).all()  # same residues as the canonical input
+        # key switch with every digit and key residue at q - 1, then random
+        for trial in range(3):
+            key = O.uniform_rns(rng, primes, (k - 1, 2), n)
+            L = k - 1
+            ct = O.uniform_rns(rng, primes[:L], (2, 2), n)
+            tgt = O.uniform_rns(rng, primes[:L], (2,), n)
+            if trial == 0:
+                for i in range(k):
+                    key[:, :, i, :] = primes[i] - 1
+                # the target is in NTT form: choose it so that its INTT (the digits) is all q - 1
+                coeff = np.stack([np.full(n, primes[i] - 1, dtype=np.uint64) for i in range(L)])
+                tgt[0] = octx.ntt(coeff[None], L)[0]
+            dct, dt, dkey = up(moai, ct), up(moai, tgt), up(moai, key)
+            ctx.switch_key(dct, dt, dkey, L, 2)
+            got = dct.to_numpy(ct.shape)
+            for b in range(2):
+                assert (got[b] == octx.switch_key(ct[b], tgt[b], key, L).reshape(2, L, n)).all(), (trial, b)
+    finally:
+        moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 16)

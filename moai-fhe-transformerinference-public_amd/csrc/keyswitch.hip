@@ -382,9 +382,15 @@ static int check_level(const moai_ctx *c, size_t L, size_t polys)
     return MOAI_OK;
 }
 
+struct KsTarget
+{
+    const uint64_t *ptr; // NTT-form target rows
+    uint32_t stride_rows, off_rows;
+};
+
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, hipStream_t s);
+                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, const KsTarget &tg, hipStream_t s);
 
 // number of output moduli whose digits are in flight at once: bounded by the scratch budget
 // (MOAI_KS_TMP_MB, default 8192 MiB) so that small batches expose (L+1) x 16 tiles of parallelism in
@@ -478,7 +484,7 @@ static int ks_mode(const moai_ctx *c, uint32_t prime, size_t L, bool allow_fp)
 
 template <int LOGN, int MODE>
 static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                               size_t batch, const KsGroup &grp, size_t G, uint32_t splits, hipStream_t s)
+                               size_t batch, const KsGroup &grp, size_t G, uint32_t splits, const KsTarget &tg, hipStream_t s)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     KsP1Args p1;
@@ -494,6 +500,9 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     MOAI_LAUNCH_CHECK();
     KsP2Args p2;
     p2.tmp = tmp;
+    p2.tgt = tg.ptr;
+    p2.tgt_stride = tg.stride_rows;
+    p2.tgt_off = tg.off_rows;
     p2.key = key;
     p2.acc = acc;
     p2.tw = MODE >= M_FPN ? c->fwd_twf : c->fwd_tw;
@@ -515,14 +524,14 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
 
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
-                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, hipStream_t s)
+                          size_t batch, const KsGroup &grp, size_t G, uint32_t splits, int mode, const KsTarget &tg, hipStream_t s)
 {
     switch (mode)
     {
-    case M_FPN: return ks_fused_group_mode<LOGN, M_FPN>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
-    case M_FPR: return ks_fused_group_mode<LOGN, M_FPR>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
-    case M_NOGUARD: return ks_fused_group_mode<LOGN, M_NOGUARD>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
-    default: return ks_fused_group_mode<LOGN, M_GUARD>(c, t, tmp, key, acc, L, batch, grp, G, splits, s);
+    case M_FPN: return ks_fused_group_mode<LOGN, M_FPN>(c, t, tmp, key, acc, L, batch, grp, G, splits, tg, s);
+    case M_FPR: return ks_fused_group_mode<LOGN, M_FPR>(c, t, tmp, key, acc, L, batch, grp, G, splits, tg, s);
+    case M_NOGUARD: return ks_fused_group_mode<LOGN, M_NOGUARD>(c, t, tmp, key, acc, L, batch, grp, G, splits, tg, s);
+    default: return ks_fused_group_mode<LOGN, M_GUARD>(c, t, tmp, key, acc, L, batch, grp, G, splits, tg, s);
     }
 }
 
@@ -583,6 +592,10 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         // every mode is one more pair of launches: a few ciphertexts at a low level are launch-bound and stay
         // on the single integer group (measured: FP64 pays from about 16 digit rows per call)
         const bool allow_fp = (long)(batch * L) >= tuning("MOAI_KS_FP_MIN_ROWS", 16);
+        KsTarget tg;
+        tg.ptr = target;
+        tg.stride_rows = (uint32_t)target_stride_rows;
+        tg.off_rows = (uint32_t)target_off_rows;
         std::vector<uint16_t> order;
         std::vector<int> order_mode;
         for (int mode = M_FPR; mode >= M_GUARD; --mode)
@@ -615,19 +628,19 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             switch (c->logn)
             {
             case 12:
-                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
+                rc = ks_fused_group<12>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, tg, s);
                 break;
             case 13:
-                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
+                rc = ks_fused_group<13>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, tg, s);
                 break;
             case 14:
-                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
+                rc = ks_fused_group<14>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, tg, s);
                 break;
             case 15:
-                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
+                rc = ks_fused_group<15>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, tg, s);
                 break;
             default:
-                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, s);
+                rc = ks_fused_group<16>(c, t, ops, key, acc, L, batch, grp, g, splits, mode, tg, s);
                 break;
             }
             if (rc)

@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
     const uint32_t J = w % a.L;
     const uint32_t b = w / a.L;
     const uint32_t prime = a.grp.prime[g];
+    if (a.grp.slot[g] == J)
+    {
+        // output modulus = the digit's own prime: the transform of the reduced digit is the target's NTT-form row
+        // itself (the reference copies it, SEAL/evaluator.cpp:2836-2839); ks_contig_mac8 reads it from there
+        return;
+    }
     const PrimeConst *pc = a.pc + prime;
     const uint64_t *in = a.t + (((size_t)b * a.L + J) << LOGN);
     uint64_t *out = a.tmp + ((((size_t)b * a.G + g) * a.L + J) << LOGN);
@@ -93,6 +99,8 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
 struct KsP2Args
 {
     const uint64_t *tmp; // [B][G][L][N]
+    const uint64_t *tgt; // the target in NTT form: row (b, J) at tgt + ((b * tgt_stride + tgt_off + J) << LOGN)
+    uint32_t tgt_stride, tgt_off;
     const uint64_t *key; // [k-1][2][k][N]
     uint64_t *acc;       // [B][2][L+1][N]
     const Tw *tw;
@@ -188,6 +196,22 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
         const uint32_t ch0 = (b << 7) | (r << 2);
         const uint64_t *__restrict__ base = dig + ((size_t)J << LOGN);
         uint64_t x[8];
+        const bool direct = (slot == J); // workgroup-uniform
+        if (direct)
+        {
+            // digit under its own prime: canonical NTT-form values straight from the target row
+            const ulonglong2 *__restrict__ trow =
+                reinterpret_cast<const ulonglong2 *>(a.tgt + (((size_t)bq * a.tgt_stride + a.tgt_off + J) << LOGN)) + ((size_t)tile << 10) + ch0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                ulonglong2 v = trow[c];
+                x[2 * c] = v.x;
+                x[2 * c + 1] = v.y;
+            }
+        }
+        else
+        {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
         {
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 }
             }
         }
+        } // !direct
         const ulonglong2 *__restrict__ k0 =
             reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
         const ulonglong2 *__restrict__ k1 =
@@ -296,7 +321,8 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-                const double vx = fp_red(u2d(x[2 * c]), qd, qinv), vy = fp_red(u2d(x[2 * c + 1]), qd, qinv);
+                const double vx = fp_red(direct ? fp_from_u64(x[2 * c]) : u2d(x[2 * c]), qd, qinv);
+                const double vy = fp_red(direct ? fp_from_u64(x[2 * c + 1]) : u2d(x[2 * c + 1]), qd, qinv);
                 const ulonglong2 ka = k0[c];
                 const ulonglong2 kb = k1[c];
                 double s0 = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u64(ka.x), qd, qinv);
@@ -323,7 +349,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             for (int c = 0; c < 4; ++c)
             {
                 uint64_t vx = x[2 * c], vy = x[2 * c + 1];
-                if (MODE == M_GUARD)
+                if (MODE == M_GUARD && !direct)
                 {
                     vx = csub(csub(vx, bq2), q);
                     vy = csub(csub(vy, bq2), q);

@@ -455,4 +455,168 @@ namespace moai_fused
         seal_context.sync(); // the staging buffers go out of scope
         return output;
     }
+    // moai_fused::ct_ct_matrix_mul_diagpacking replaces include/source/matrix_mul/Ct_ct_matrix_mul.hpp:58-153
+    // (softmax(QK^T) V): same arguments, same ciphertexts bit for bit.  The rotations of X that share a step, the
+    // baby-step rotations of all columns of W, the relinearize / rescale of all partial products and the giant-step
+    // rotations each run as batched calls; the products of a (column, giant step) pair are one moai_ct_dot.
+    inline std::vector<seal::Ciphertext> ct_ct_matrix_mul_diagpacking(const std::vector<seal::Ciphertext> &enc_X,
+                                                                      const std::vector<seal::Ciphertext> &enc_W,
+                                                                      const seal::GaloisKeys &RotK,
+                                                                      const seal::RelinKeys &relin_keys,
+                                                                      const seal::SEALContext &seal_context, int col_X,
+                                                                      int row_X, int col_W, int row_W, int num_batch)
+    {
+        using namespace seal;
+        (void)row_W;
+        const double scale = enc_X[0].scale();
+        std::vector<Ciphertext> output(static_cast<std::size_t>(col_W));
+        // Ct_ct_matrix_mul.hpp:71-79
+        int g = static_cast<int>(std::sqrt(static_cast<double>(col_X)));
+        if (g * g < col_X)
+        {
+            g++;
+        }
+        int b = col_X / g;
+        if (b * g < col_X)
+        {
+            b++;
+        }
+        const parms_id_type pid = enc_X[0].parms_id();
+        auto cd = seal_context.get_context_data(pid);
+        if (!cd)
+        {
+            throw std::invalid_argument("encrypted1 is not valid for encryption parameters");
+        }
+        if (row_X < col_X)
+        {
+            throw std::logic_error("the replacement expects every diagonal of X to be present (row_X >= col_X)");
+        }
+        for (int i = 0; i < col_X; i++)
+        {
+            const Ciphertext &c = enc_X[static_cast<std::size_t>(i)];
+            if (c.parms_id() != pid || c.size() != 2 || !c.is_ntt_form() || c.scale() != scale)
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            }
+        }
+        for (int i = 0; i < col_W; i++)
+        {
+            const Ciphertext &c = enc_W[static_cast<std::size_t>(i)];
+            if (c.parms_id() != pid || c.size() != 2 || !c.is_ntt_form() || c.scale() != enc_W[0].scale())
+            {
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            }
+        }
+        if (RotK.parms_id() != seal_context.key_parms_id())
+        {
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        }
+        if (relin_keys.parms_id() != seal_context.key_parms_id() || relin_keys.size() < 1)
+        {
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        }
+        if (!cd->next_context_data())
+        {
+            throw std::invalid_argument("end of modulus switching chain reached");
+        }
+        const double new_scale = scale * enc_W[0].scale();
+        if (new_scale <= 0 || (static_cast<int>(std::log2(new_scale)) >= cd->total_coeff_modulus_bit_count()))
+        {
+            throw std::invalid_argument("scale out of bounds");
+        }
+        const std::size_t L = cd->parms().coeff_modulus().size(), n = seal_context.n();
+        const std::size_t ctw = 2 * L * n, G = static_cast<std::size_t>(g), Bg = static_cast<std::size_t>(b);
+        const std::size_t cols = static_cast<std::size_t>(col_W), nx = static_cast<std::size_t>(col_X);
+        void *st = seal_context.stream();
+        moai_ctx *dev = seal_context.device();
+        std::vector<std::uint32_t> seq;
+        auto rotate = [&](std::uint64_t *data, int step, std::size_t count) {
+            // Evaluator::rotate_vector on `count` contiguous ciphertexts
+            seq.clear();
+            detail::rotation_sequence(seal_context, RotK, step, seq);
+            for (std::uint32_t elt : seq)
+            {
+                util::hip_check(moai_apply_galois(dev, data, L, elt, RotK.device_key(GaloisKeys::get_index(elt)), count, st));
+            }
+        };
+        // rot_enc_X[index], index = i*g + j: enc_X[index] rotated by (col_X - i*g) * num_batch (:86-101)
+        util::DeviceArray rx(Bg * G * ctw, st);
+        for (std::size_t idx = 0; idx < nx; idx++)
+        {
+            util::hip_check(moai_memcpy_d2d(rx.get() + idx * ctw, enc_X[idx].device_data(), ctw * 8, st));
+        }
+        if (Bg * G > nx)
+        {
+            util::hip_check(moai_memset_zero(rx.get() + nx * ctw, (Bg * G - nx) * ctw * 8, st));
+        }
+        for (std::size_t i = 0; i < Bg; i++)
+        {
+            const int rot_ind = (col_X - static_cast<int>(i * G)) * num_batch;
+            const std::size_t first = i * G, count = std::min(G, nx > first ? nx - first : 0);
+            if (count && rot_ind != col_X * num_batch)
+            {
+                rotate(rx.get() + first * ctw, rot_ind, count);
+            }
+        }
+        // baby steps: c_g[i][k] = enc_W[i] rotated by k * num_batch (:107-113), stored [i][k]
+        util::DeviceArray cg(cols * G * ctw, st), stage(cols * ctw, st);
+        for (std::size_t i = 0; i < cols; i++)
+        {
+            util::hip_check(moai_memcpy_d2d(stage.get() + i * ctw, enc_W[i].device_data(), ctw * 8, st));
+        }
+        for (std::size_t k = 0; k < G; k++)
+        {
+            util::DeviceArray rot(cols * ctw, st);
+            util::hip_check(moai_memcpy_d2d(rot.get(), stage.get(), cols * ctw * 8, st));
+            if (k)
+            {
+                rotate(rot.get(), static_cast<int>(k) * num_batch, cols);
+            }
+            for (std::size_t i = 0; i < cols; i++)
+            {
+                util::hip_check(moai_memcpy_d2d(cg.get() + (i * G + k) * ctw, rot.get() + i * ctw, ctw * 8, st));
+            }
+        }
+        // giant steps: out[i][j] = sum_k c_g[i][k] * rot_enc_X[j*g + k] (:116-141), all relinearized and rescaled together
+        util::DeviceArray d3(cols * Bg * 3 * L * n, st);
+        for (std::size_t i = 0; i < cols; i++)
+        {
+            for (std::size_t j = 0; j < Bg; j++)
+            {
+                const std::size_t first = j * G, count = std::min(G, nx > first ? nx - first : 0);
+                if (!count)
+                {
+                    throw std::logic_error("empty giant step");
+                }
+                util::hip_check(moai_ct_dot(dev, cg.get() + i * G * ctw, rx.get() + first * ctw, d3.get() + (j * cols + i) * 3 * L * n,
+                                            count, L, st));
+            }
+        }
+        util::DeviceArray d2(cols * Bg * ctw, st), dres(cols * Bg * 2 * (L - 1) * n, st);
+        util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0), d2.get(), L, cols * Bg, st));
+        util::hip_check(moai_rescale(dev, d2.get(), dres.get(), 2, L, cols * Bg, st));
+        // output[i] = out[i][0] + sum_{j>=1} rotate(out[i][j], j*g*num_batch) (:142-150); layout [j][i]
+        const std::size_t Lr = L - 1, rw = 2 * Lr * n;
+        for (std::size_t j = 1; j < Bg; j++)
+        {
+            std::uint64_t *blk = dres.get() + j * cols * rw;
+            seq.clear();
+            detail::rotation_sequence(seal_context, RotK, static_cast<int>(j * G) * num_batch, seq);
+            for (std::uint32_t elt : seq)
+            {
+                util::hip_check(moai_apply_galois(dev, blk, Lr, elt, RotK.device_key(GaloisKeys::get_index(elt)), cols, st));
+            }
+            util::hip_check(moai_add(dev, dres.get(), blk, dres.get(), cols * 2, Lr, st));
+        }
+        const parms_id_type next_id = cd->next_context_data()->parms_id();
+        for (std::size_t i = 0; i < cols; i++)
+        {
+            output[i].resize(seal_context, next_id, 2);
+            util::hip_check(moai_memcpy_d2d(output[i].device_data(), dres.get() + i * rw, rw * 8, st));
+            output[i].is_ntt_form() = true;
+            output[i].scale() = scale; // :139
+        }
+        seal_context.sync();
+        return output;
+    }
 } // namespace moai_fused

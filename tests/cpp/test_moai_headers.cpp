@@ -230,6 +230,32 @@ int main()
         }
     }
 
+    // ---- ct_ct_matrix_mul_diagpacking (softmax(QK^T) V): the batched replacement against MOAI's loop ---------
+    {
+        const int dx = 5, dw = 3, nb = 4; // g = 3, b = 2: a full and a partial giant step
+        Encryptor encryptor(context, pk);
+        vector<Ciphertext> ex(dx), ew(dw);
+        for (int j = 0; j < max(dx, dw); j++)
+        {
+            vector<double> v(slots);
+            for (size_t s = 0; s < slots; s++)
+                v[s] = 0.3 * cos(0.013 * s + 0.7 * j);
+            Plaintext p;
+            encoder.encode(v, scale, p);
+            if (j < dx) encryptor.encrypt(p, ex[j]);
+            if (j < dw) encryptor.encrypt(p, ew[j]);
+        }
+        vector<Ciphertext> o1 = ct_ct_matrix_mul_diagpacking(ex, ew, gal_keys, relin_keys, context, dx, dx, dw, dx, nb);
+        vector<Ciphertext> o2 = moai_fused::ct_ct_matrix_mul_diagpacking(ex, ew, gal_keys, relin_keys, context, dx, dx, dw, dx, nb);
+        CHECK(o1.size() == o2.size());
+        for (int i = 0; i < dw; i++)
+        {
+            CHECK(o1[i].parms_id() == o2[i].parms_id());
+            CHECK(o1[i].scale() == o2[i].scale());
+            CHECK(o1[i].download() == o2[i].download());
+        }
+    }
+
     // ---- gelu_v2 (degree-24 polynomial, the GELU the 12-layer run uses: test_full_scheme.hpp:886) ----
     {
         Encryptor encryptor(context, pk);

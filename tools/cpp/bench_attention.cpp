@@ -224,6 +224,20 @@ int main(int argc, char **argv)
     context.sync();
     double t_sv = now_s() - t0;
     printf("softmax(QK^T) V (diagpacking, chain index %zu): %8.3f s\n", context.get_context_data(V[0].parms_id())->chain_index(), t_sv);
+    {
+        vector<Ciphertext> outf;
+        double t_f = 0;
+        for (int rep = 0; rep < 2; rep++)
+        {
+            t0 = now_s();
+            outf = moai_fused::ct_ct_matrix_mul_diagpacking(enc_softmax, V, gal_keys, relin_keys, context, tokens, tokens, col_W, tokens, num_batch);
+            context.sync();
+            t_f = now_s() - t0;
+        }
+        bool same = true;
+        for (int i : { 0, 31, 63 }) same = same && (outf[i].download() == out[i].download());
+        printf("softmax(QK^T) V again, batched:                 %8.3f s (%s MOAI's loop)\n", t_f, same ? "bit-identical to" : "DIFFERS from");
+    }
 
     // ---- self-output product (test_full_scheme.hpp:601): 768 x 768 with vector-encoded masked weights, on the
     // concatenated head outputs (chain index of the .V result) ---------------------------------------------------

@@ -1,6 +1,6 @@
+set -e
 cd /root/repo
-for w in 150 500 1500 4000; do
-echo "== window $w us"
-MOAI_SHIM_COMBINE_US=$w timeout -k 10 600 tools/cpp/bench_bootstrap_lt 32 16 2>&1 | tail -2 | head -1
-MOAI_SHIM_COMBINE_US=$w timeout -k 10 900 tools/cpp/bench_attention 16 768 2>&1 | grep "Q K^T (col\|softmax(QK\|gelu_v2 on 16"
-done
+timeout -k 10 300 tests/cpp/test_moai_headers > gpurun_out/test_moai_headers.log 2>&1 || { tail -30 gpurun_out/test_moai_headers.log; exit 1; }
+tail -1 gpurun_out/test_moai_headers.log
+timeout -k 10 900 tools/cpp/bench_attention 16 768 > gpurun_out/attention.txt 2>&1 || { tail -20 gpurun_out/attention.txt; exit 1; }
+cat gpurun_out/attention.txt

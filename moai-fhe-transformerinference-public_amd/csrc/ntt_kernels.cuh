@@ -397,6 +397,15 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
     const uint32_t blk = (tile << 4) + b;
     const Tw *__restrict__ twbt = twb + (size_t)tile * (15 * 256);
 
+    // the per-thread twiddles of the first four stages do not depend on the data: fetch them while the tile is
+    // staged through LDS instead of one by one behind the barrier (-3.7 % on the inverse transform; the same
+    // prefetch in the forward passes costs registers they do not have and measured slower)
+    Tw tb[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i)
+    {
+        tb[i] = twbt[((uint32_t)i << 8) + tid];
+    }
     const ulonglong2 *__restrict__ in2 = reinterpret_cast<const ulonglong2 *>(base);
 #pragma unroll
     for (int it = 0; it < 8; ++it)
@@ -424,7 +433,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
         {
             if (!(j & half))
             {
-                Tw t = twbt[(((1u << (u - 4)) - 1u + (uint32_t)(j >> (8 - u))) << 8) + tid];
+                Tw t = tb[(1 << (u - 4)) - 1 + (j >> (8 - u))];
                 gs_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }

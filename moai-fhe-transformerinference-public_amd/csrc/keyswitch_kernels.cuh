@@ -182,6 +182,28 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
     }
     const uint64_t *__restrict__ dig = a.tmp + ((((size_t)bq * a.G + g) * a.L) << LOGN) + ((size_t)tile << 11);
 
+    // FP64 modes: the thirteen per-thread twiddles of stages 3..7 are the same for every digit of the loop (they
+    // depend on the prime, the tile and the thread only) -- 26 registers instead of 13 loads behind the two LDS
+    // barriers of every iteration
+    double twr[13];
+    if (MODE >= M_FPN)
+    {
+        const uint32_t b = tid0 >> 5, r = tid0 & 31u, hi3 = r >> 2;
+        const uint32_t blk = (tile << 3) + b;
+        twr[0] = tw1[(1u << (R1 + 3)) + (blk << 3) + hi3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            twr[1 + i] = tw1[(1u << (R1 + 4)) + (blk << 4) + ((hi3 << 1) | (uint32_t)i)];
+            twr[7 + i] = tw1[(1u << (R1 + 6)) + (blk << 6) + ((r << 1) | (uint32_t)i)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            twr[3 + i] = tw1[(1u << (R1 + 5)) + (blk << 5) + ((hi3 << 2) | (uint32_t)i)];
+            twr[9 + i] = tw1[(1u << (R1 + 7)) + (blk << 7) + ((r << 2) | (uint32_t)i)];
+        }
+    }
     for (uint32_t J = j0; J < j1; ++J)
     {
         // opaque copy of the thread index: keeps the per-thread address arithmetic inside the loop instead of
@@ -261,7 +283,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                     uint32_t t_ = (hi3 << 5) | ((uint32_t)j << 2) | lo2;
                     if (MODE >= M_FPN)
                     {
-                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))], u2d(bq1), u2d(bq2));
+                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], twr[(u == 3) ? 0 : (u == 4) ? 1 + (j >> 2) : 3 + (j >> 1)], u2d(bq1), u2d(bq2));
                     }
                     else
                     {
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                     uint32_t t_ = (r << 3) | (uint32_t)j;
                     if (MODE >= M_FPN)
                     {
-                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (t_ >> (8 - u))], u2d(bq1), u2d(bq2));
+                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], twr[(u == 6) ? 7 + (j >> 2) : 9 + (j >> 1)], u2d(bq1), u2d(bq2));
                     }
                     else
                     {

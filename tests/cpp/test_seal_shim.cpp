@@ -6,8 +6,10 @@
 #include <iostream>
 
 #include "seal/seal.h"
+#include "seal/moai_fused.h"
 
 #include <omp.h>
+#include <random>
 
 using namespace seal;
 using namespace std;
@@ -392,6 +394,117 @@ static void concurrent_callers()
     }
 }
 
+// Packed ciphertexts (moai_fused::pack): a random program of evaluator calls applied to a pack of four must give,
+// for every member, what the same program gives on that member alone.
+static void packed_random_program()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t n = 4096;
+    parms.set_poly_modulus_degree(n);
+    parms.set_coeff_modulus(CoeffModulus::Create(n, { 51, 46, 46, 46, 46, 51, 58 }));
+    parms.set_secret_key_hamming_weight(64);
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    RelinKeys rk;
+    keygen.create_relin_keys(rk);
+    GaloisKeys gk;
+    keygen.create_galois_keys(gk);
+    CKKSEncoder encoder(context);
+    Encryptor encryptor(context, pk);
+    Evaluator evaluator(context, encoder);
+    const double scale = pow(2.0, 46);
+    const int B = 4;
+    vector<Ciphertext> in(B);
+    for (int b = 0; b < B; b++)
+    {
+        vector<double> v(encoder.slot_count());
+        for (size_t s = 0; s < v.size(); s++) v[s] = 0.3 + 0.05 * b + 1e-4 * (double)(s % 31);
+        Plaintext p;
+        encoder.encode(v, scale, p);
+        encryptor.encrypt(p, in[b]);
+    }
+    vector<double> pv(encoder.slot_count());
+    for (size_t s = 0; s < pv.size(); s++) pv[s] = 0.5 - 1e-3 * (double)(s % 7);
+    std::mt19937 rng(123);
+    for (int trial = 0; trial < 6; trial++)
+    {
+        vector<int> prog(10);
+        for (auto &o : prog) o = (int)(rng() % 9);
+        auto run = [&](Ciphertext x) {
+            Ciphertext y = x;
+            for (int o : prog)
+            {
+                auto cd = context.get_context_data(x.parms_id());
+                const bool can_rescale = cd->chain_index() > 1;
+                switch (o)
+                {
+                case 0: evaluator.add_inplace(x, y); break;
+                case 1: evaluator.sub_inplace(x, y); evaluator.add_inplace(x, y); evaluator.negate_inplace(x); evaluator.negate_inplace(x); break;
+                case 2:
+                    if (can_rescale)
+                    {
+                        evaluator.multiply_inplace(x, y);
+                        evaluator.relinearize_inplace(x, rk);
+                        evaluator.rescale_to_next_inplace(x);
+                        x.scale() = scale;
+                        evaluator.mod_switch_to_inplace(y, x.parms_id());
+                    }
+                    break;
+                case 3: evaluator.rotate_vector_inplace(x, 1 + (int)(trial % 5), gk); break;
+                case 4: evaluator.rotate_vector_inplace(x, -3, gk); break;
+                case 5:
+                    if (can_rescale)
+                    {
+                        Plaintext p;
+                        encoder.encode(pv, x.parms_id(), x.scale(), p);
+                        evaluator.multiply_plain_inplace(x, p);
+                        evaluator.rescale_to_next_inplace(x);
+                        x.scale() = scale;
+                        evaluator.mod_switch_to_inplace(y, x.parms_id());
+                    }
+                    break;
+                case 6:
+                {
+                    Plaintext p;
+                    encoder.encode(0.125, x.parms_id(), x.scale(), p);
+                    evaluator.add_plain_inplace(x, p);
+                    Plaintext pvv;
+                    encoder.encode(pv, x.parms_id(), x.scale(), pvv);
+                    evaluator.sub_plain_inplace(x, pvv);
+                    break;
+                }
+                case 7:
+                    if (can_rescale)
+                    {
+                        evaluator.square_inplace(x);
+                        evaluator.relinearize_inplace(x, rk);
+                        evaluator.rescale_to_next_inplace(x);
+                        x.scale() = scale;
+                        evaluator.mod_switch_to_inplace(y, x.parms_id());
+                    }
+                    break;
+                default: evaluator.complex_conjugate_inplace(x, gk); break;
+                }
+            }
+            return x;
+        };
+        Ciphertext packed = moai_fused::pack(in, context);
+        Ciphertext rp = run(packed);
+        vector<Ciphertext> parts;
+        moai_fused::unpack(rp, context, parts);
+        CHECK(parts.size() == (size_t)B);
+        for (int b = 0; b < B; b++)
+        {
+            Ciphertext r1 = run(in[b]);
+            CHECK(r1.parms_id() == parts[b].parms_id());
+            CHECK(r1.scale() == parts[b].scale());
+            CHECK(r1.download() == parts[b].download());
+        }
+    }
+}
+
 int main()
 {
     try
@@ -399,6 +512,7 @@ int main()
         config1();
         evaluator_ops();
         concurrent_callers();
+        packed_random_program();
     }
     catch (const std::exception &e)
     {

@@ -162,15 +162,10 @@ namespace moai_fused
                 return;
             }
             const parms_id_type pid = in[0].parms_id();
-            auto cd = context_.get_context_data(pid);
-            if (!cd)
-            {
-                throw std::invalid_argument("encrypted is not valid for encryption parameters");
-            }
             const double scale = in[0].scale();
             for (auto &c : in)
             {
-                if (c.parms_id() != pid || c.scale() != scale)
+                if (c.parms_id() != pid || c.scale() != scale || c.batch() != 1)
                 {
                     throw std::invalid_argument("the batch must share one level and one scale");
                 }
@@ -178,6 +173,63 @@ namespace moai_fused
                 {
                     throw std::invalid_argument("encrypted must be a size-2 ciphertext in NTT form");
                 }
+            }
+            const std::size_t ct_words = 2 * in[0].coeff_modulus_size() * context_.n();
+            void *st = context_.stream();
+            run(
+                pid, scale, B, gal_keys,
+                [&](std::uint64_t *src) {
+                    for (std::size_t b = 0; b < B; b++)
+                    {
+                        util::hip_check(moai_memcpy_d2d(src + b * ct_words, in[b].device_data(), ct_words * 8, st));
+                    }
+                },
+                [&](const std::uint64_t *acc, double new_scale) {
+                    for (std::size_t b = 0; b < B; b++)
+                    {
+                        result[b].resize(context_, pid, 2);
+                        util::hip_check(moai_memcpy_d2d(result[b].device_data(), acc + b * ct_words, ct_words * 8, st));
+                        result[b].is_ntt_form() = true;
+                        result[b].scale() = new_scale;
+                    }
+                });
+            out = std::move(result);
+        }
+
+        // the same on a packed ciphertext (moai_fused::pack): out may be the input object
+        void apply(const seal::Ciphertext &in, seal::Ciphertext &out, const seal::GaloisKeys &gal_keys)
+        {
+            using namespace seal;
+            if (in.size() != 2 || !in.is_ntt_form())
+            {
+                throw std::invalid_argument("encrypted must be a size-2 ciphertext in NTT form");
+            }
+            const parms_id_type pid = in.parms_id();
+            const std::size_t B = in.batch();
+            const std::size_t batch_words = B * 2 * in.coeff_modulus_size() * context_.n();
+            void *st = context_.stream();
+            Ciphertext result;
+            run(
+                pid, in.scale(), B, gal_keys,
+                [&](std::uint64_t *src) { util::hip_check(moai_memcpy_d2d(src, in.device_data(), batch_words * 8, st)); },
+                [&](const std::uint64_t *acc, double new_scale) {
+                    result.resize_batch(context_, pid, 2, B);
+                    util::hip_check(moai_memcpy_d2d(result.device_data(), acc, batch_words * 8, st));
+                    result.is_ntt_form() = true;
+                    result.scale() = new_scale;
+                });
+            out = std::move(result);
+        }
+
+    private:
+        template <typename Load, typename Store>
+        void run(const seal::parms_id_type &pid, double scale, std::size_t B, const seal::GaloisKeys &gal_keys, Load load, Store store)
+        {
+            using namespace seal;
+            auto cd = context_.get_context_data(pid);
+            if (!cd)
+            {
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
             }
             if (gal_keys.parms_id() != context_.key_parms_id())
             {
@@ -213,10 +265,7 @@ namespace moai_fused
                 src_own.resize(batch_words, st);
                 src = src_own.get();
             }
-            for (std::size_t b = 0; b < B; b++)
-            {
-                util::hip_check(moai_memcpy_d2d(src + b * ct_words, in[b].device_data(), ct_words * 8, st));
-            }
+            load(src);
             std::vector<std::uint32_t> seq;
             for (std::size_t k = 0; k < nb; k++)
             {
@@ -254,18 +303,10 @@ namespace moai_fused
                     util::hip_check(moai_add(dev, acc.get(), dst, acc.get(), B * 2, L, st));
                 }
             }
-            for (std::size_t b = 0; b < B; b++)
-            {
-                result[b].resize(context_, pid, 2);
-                util::hip_check(moai_memcpy_d2d(result[b].device_data(), acc.get() + b * ct_words, ct_words * 8, st));
-                result[b].is_ntt_form() = true;
-                result[b].scale() = new_scale;
-            }
+            store(acc.get(), new_scale);
             context_.sync(); // staging buffers go out of scope
-            out = std::move(result);
         }
 
-    private:
         struct Giant
         {
             int step = 0;

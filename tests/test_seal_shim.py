@@ -46,10 +46,18 @@ def test_cpp_test_binaries_are_built():
     assert os.path.exists(os.path.join(CPP, "test_seal_shim"))
     assert os.path.exists(os.path.join(CPP, "test_moai_headers"))
     assert os.path.exists(os.path.join(CPP, "test_bootstrap_lt"))
+    assert os.path.exists(os.path.join(CPP, "test_bootstrap_eval"))
+
+
+def test_bootstrap_polynomial_heap_host_checks():
+    """babycount, the quotient / remainder heap of the modular-reduction polynomial and the rotation-key list:
+    host arithmetic only (tests/cpp/test_bootstrap_eval.cpp, part 1); the device parts run under -m gpu."""
+    r = subprocess.run([os.path.join(CPP, "test_bootstrap_eval"), "--host-only"], cwd=CPP, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ALL PASS" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers", "test_bootstrap_lt"])
+@pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers", "test_bootstrap_lt", "test_bootstrap_eval"])
 def test_cpp_binary_passes_on_gpu(binary):
     if binary == "test_moai_headers" and not os.path.exists(os.path.join(CPP, binary)) and not os.path.isdir(REF):
         pytest.skip("built from MOAI's own headers, which only the build container holds")

@@ -121,8 +121,8 @@ namespace seal
         }
 
         // ---- multiply / square / relinearize -----------------------------------------------------------
-        void multiply_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2,
-                              MemoryPoolHandle = MemoryPoolHandle()) const
+        // SEAL/evaluator.cpp:770-909 (ckks_multiply) / :1223-1282 (ckks_square); `out` must not be an operand
+        void multiply_into(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &out) const
         {
             check_ct(encrypted1, "encrypted1");
             check_ct(encrypted2, "encrypted2");
@@ -149,7 +149,6 @@ namespace seal
                 throw std::invalid_argument("encrypted1 and encrypted2 pack different numbers of ciphertexts");
             }
             const std::size_t L = encrypted1.coeff_modulus_size(), B = encrypted1.batch();
-            Ciphertext out;
             out.resize_batch(context_, encrypted1.parms_id(), 3, B);
             if (&encrypted1 == &encrypted2 || encrypted1.device_data() == encrypted2.device_data())
             {
@@ -162,20 +161,21 @@ namespace seal
             }
             out.is_ntt_form() = true;
             out.scale() = new_scale;
+        }
+        void multiply_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2,
+                              MemoryPoolHandle = MemoryPoolHandle()) const
+        {
+            Ciphertext out;
+            multiply_into(encrypted1, encrypted2, out);
             encrypted1 = std::move(out);
         }
         void multiply(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination,
                       MemoryPoolHandle = MemoryPoolHandle()) const
         {
-            if (&encrypted2 == &destination)
-            {
-                multiply_inplace(destination, encrypted1);
-            }
-            else
-            {
-                destination = encrypted1;
-                multiply_inplace(destination, encrypted2);
-            }
+            // the product is built in a fresh ciphertext either way: no deep copy of an operand first
+            Ciphertext out;
+            multiply_into(encrypted1, encrypted2, out);
+            destination = std::move(out);
         }
         void square_inplace(Ciphertext &encrypted, MemoryPoolHandle = MemoryPoolHandle()) const
         {
@@ -183,8 +183,9 @@ namespace seal
         }
         void square(const Ciphertext &encrypted, Ciphertext &destination, MemoryPoolHandle = MemoryPoolHandle()) const
         {
-            destination = encrypted;
-            square_inplace(destination);
+            Ciphertext out;
+            multiply_into(encrypted, encrypted, out);
+            destination = std::move(out);
         }
         void relinearize_inplace(Ciphertext &encrypted, const RelinKeys &relin_keys,
                                  MemoryPoolHandle = MemoryPoolHandle()) const
@@ -609,8 +610,10 @@ namespace seal
         }
         void multiply_const(const Ciphertext &encrypted, double value, Ciphertext &destination) const
         {
-            destination = encrypted;
-            multiply_const_inplace(destination, value);
+            Plaintext const_plain;
+            encoder_.encode(value, encrypted.scale(), const_plain);
+            mod_switch_to_inplace(const_plain, encrypted.parms_id());
+            multiply_plain(encrypted, const_plain, destination);
         }
         template <typename T>
         void multiply_vector_inplace(Ciphertext &encrypted, const std::vector<T> &value) const
@@ -623,8 +626,10 @@ namespace seal
         template <typename T>
         void multiply_vector(const Ciphertext &encrypted, const std::vector<T> &value, Ciphertext &destination) const
         {
-            destination = encrypted;
-            multiply_vector_inplace(destination, value);
+            Plaintext vector_plain;
+            encoder_.encode(value, encrypted.scale(), vector_plain);
+            mod_switch_to_inplace(vector_plain, encrypted.parms_id());
+            multiply_plain(encrypted, vector_plain, destination);
         }
         // SEAL/evaluator.h:1371-1378
         template <typename T>
@@ -639,8 +644,10 @@ namespace seal
         void multiply_vector_reduced_error(const Ciphertext &encrypted, const std::vector<T> &value,
                                            Ciphertext &destination) const
         {
-            destination = encrypted;
-            multiply_vector_inplace_reduced_error(destination, value);
+            Plaintext plain;
+            encoder_.encode(value, encrypted.scale(), plain);
+            mod_switch_to_inplace(plain, encrypted.parms_id());
+            multiply_plain(encrypted, plain, destination);
         }
         void double_inplace(Ciphertext &encrypted) const
         {

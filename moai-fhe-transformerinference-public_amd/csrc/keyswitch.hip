@@ -300,34 +300,57 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
         a.accumulate = accumulate ? 1 : 0;
         a.acc_splits = acc_splits;
         a.acc_split_stride = acc_split_stride;
-        a.total_work = (uint32_t)(P * Lout * (c->n >> 12));
-        bool noguard = true;
-        for (size_t i = 0; i < Lout && noguard; ++i)
+        // one pair of launches per arithmetic mode present among the output moduli (ntt_mode); below
+        // MOAI_MD_FP_MIN_ROWS rows the extra launches cost more than the FP64 butterflies save (a single
+        // ciphertext at MOAI's top level: 162 vs 147 ms per bootstrap; packs of 16: 66.0 vs 67.1 ms)
+        const long fp_min_rows = tuning("MOAI_MD_FP_MIN_ROWS", 256);
+        const bool allow_fp = (long)(P * Lout) >= fp_min_rows;
+        for (int mode = M_GUARD; mode <= M_FPR; ++mode)
         {
-            noguard = noguard_ok(c->primes[i]);
-        }
-#define MOAI_MD_CASE(LG)                                                                                     \
-    case LG:                                                                                                 \
-        if (noguard)                                                                                         \
-        {                                                                                                    \
-            hipLaunchKernelGGL((moddown_strided<LG, true>), dim3(a.total_work), dim3(256), 0, s, a);         \
-            hipLaunchKernelGGL((moddown_contig<LG, true>), dim3(a.total_work), dim3(256), 0, s, a);          \
-        }                                                                                                    \
-        else                                                                                                 \
-        {                                                                                                    \
-            hipLaunchKernelGGL((moddown_strided<LG, false>), dim3(a.total_work), dim3(256), 0, s, a);        \
-            hipLaunchKernelGGL((moddown_contig<LG, false>), dim3(a.total_work), dim3(256), 0, s, a);         \
-        }                                                                                                    \
+            a.Lsel = 0;
+            for (size_t i = 0; i < Lout; ++i)
+            {
+                int m = ntt_mode(c, (uint32_t)i);
+                if (m >= M_FPN && !allow_fp)
+                {
+                    m = noguard_ok(c->primes[i]) ? M_NOGUARD : M_GUARD;
+                }
+                if (m == mode)
+                {
+                    a.sel.idx[a.Lsel++] = (uint16_t)i;
+                }
+            }
+            if (!a.Lsel)
+            {
+                continue;
+            }
+            a.total_work = (uint32_t)(P * a.Lsel * (c->n >> 12));
+            a.tw = mode >= M_FPN ? c->fwd_twf : c->fwd_tw;
+            a.twb = mode >= M_FPN ? c->fwd_twfb : c->fwd_twb;
+#define MOAI_MD_MODE(LG, MD)                                                                         \
+    hipLaunchKernelGGL((moddown_strided<LG, MD>), dim3(a.total_work), dim3(256), 0, s, a);           \
+    hipLaunchKernelGGL((moddown_contig<LG, MD>), dim3(a.total_work), dim3(256), 0, s, a);
+#define MOAI_MD_CASE(LG)                                     \
+    case LG:                                                 \
+        switch (mode)                                        \
+        {                                                    \
+        case M_GUARD: MOAI_MD_MODE(LG, M_GUARD) break;       \
+        case M_NOGUARD: MOAI_MD_MODE(LG, M_NOGUARD) break;   \
+        case M_FPN: MOAI_MD_MODE(LG, M_FPN) break;           \
+        default: MOAI_MD_MODE(LG, M_FPR) break;              \
+        }                                                    \
         break;
-        switch (c->logn)
-        {
-            MOAI_MD_CASE(12)
-            MOAI_MD_CASE(13)
-            MOAI_MD_CASE(14)
-            MOAI_MD_CASE(15)
-            MOAI_MD_CASE(16)
-        }
+            switch (c->logn)
+            {
+                MOAI_MD_CASE(12)
+                MOAI_MD_CASE(13)
+                MOAI_MD_CASE(14)
+                MOAI_MD_CASE(15)
+                MOAI_MD_CASE(16)
+            }
 #undef MOAI_MD_CASE
+#undef MOAI_MD_MODE
+        }
         MOAI_LAUNCH_CHECK();
         return MOAI_OK;
     }

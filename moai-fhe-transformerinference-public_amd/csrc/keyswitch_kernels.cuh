@@ -433,6 +433,16 @@ struct LoadExpandLast
     }
 };
 
+// the same expansion for the FP64 modes: the integer result is below 2 q_i < 2^52, so the conversion is exact
+struct LoadExpandLastFp
+{
+    uint64_t ql, half, q, cr1, fix, qd, qinv;
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return d2u(fp_red(fp_from_u64(barrett64(csub(v + half, ql), q, cr1) + fix), u2d(qd), u2d(qinv)));
+    }
+};
+
 struct StoreModDown
 {
     const ulonglong2 *acc; // tile base of the row being divided (first of `splits` partial copies)
@@ -481,9 +491,11 @@ struct ModDownArgs
     uint32_t acc_splits;     // >= 1
     size_t acc_split_stride; // words between partial copies of acc
     uint32_t total_work;
+    RowMap sel;              // the output rows (= primes) of this launch: one arithmetic mode per launch
+    uint32_t Lsel;
 };
 
-template <int LOGN, bool NOGUARD>
+template <int LOGN, int MODE>
 __global__ __launch_bounds__(256, 4) void moddown_strided(ModDownArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -492,20 +504,38 @@ __global__ __launch_bounds__(256, 4) void moddown_strided(ModDownArgs a)
     uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t tile = w % TPR;
     w /= TPR;
-    const uint32_t i = w % a.Lout;
-    const uint32_t p = w / a.Lout;
+    const uint32_t i = __builtin_amdgcn_readfirstlane(a.sel.idx[w % a.Lsel]);
+    const uint32_t p = w / a.Lsel;
     const PrimeConst *pc = a.pc + i;
-    LoadExpandLast op;
-    op.ql = a.pc[a.prime_last].q;
-    op.half = op.ql >> 1;
-    op.q = pc->q;
-    op.cr1 = pc->cr1;
-    op.fix = pc->q - barrett64(op.half, pc->q, pc->cr1);
-    fwd_strided_tile<LOGN, LoadExpandLast, NOGUARD>(a.last + ((size_t)p << LOGN), a.u + (((size_t)p * a.Lout + i) << LOGN), tile,
-                                                    a.tw + ((size_t)i << LOGN), pc->q, pc->q2, lds, threadIdx.x, op);
+    const uint64_t ql = a.pc[a.prime_last].q, half = ql >> 1;
+    const uint64_t fix = pc->q - barrett64(half, pc->q, pc->cr1);
+    const uint64_t *in = a.last + ((size_t)p << LOGN);
+    uint64_t *outp = a.u + (((size_t)p * a.Lout + i) << LOGN);
+    if (MODE >= M_FPN)
+    {
+        LoadExpandLastFp op;
+        op.ql = ql;
+        op.half = half;
+        op.q = pc->q;
+        op.cr1 = pc->cr1;
+        op.fix = fix;
+        op.qd = pc->qd;
+        op.qinv = pc->qinv;
+        fwd_strided_tile<LOGN, LoadExpandLastFp, MODE>(in, outp, tile, a.tw + ((size_t)i << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+    }
+    else
+    {
+        LoadExpandLast op;
+        op.ql = ql;
+        op.half = half;
+        op.q = pc->q;
+        op.cr1 = pc->cr1;
+        op.fix = fix;
+        fwd_strided_tile<LOGN, LoadExpandLast, MODE>(in, outp, tile, a.tw + ((size_t)i << LOGN), pc->q, pc->q2, lds, threadIdx.x, op);
+    }
 }
 
-template <int LOGN, bool NOGUARD>
+template <int LOGN, int MODE>
 __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -515,19 +545,20 @@ __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
     const uint32_t p = w % a.P;
     w /= a.P;
     const uint32_t tile = w % TPR;
-    const uint32_t i = w / TPR;
-    const PrimeConst *pc = a.pc + i;
+    const uint32_t i = __builtin_amdgcn_readfirstlane(a.sel.idx[w / TPR]);
+    const PrimeConst &pc = a.pc[i];
     StoreModDown st;
     st.acc = reinterpret_cast<const ulonglong2 *>(a.acc + (((size_t)p * a.acc_stride + i) << LOGN)) + ((size_t)tile << 11);
     st.out = reinterpret_cast<ulonglong2 *>(a.out + (((size_t)p * a.Lout + i) << LOGN)) + ((size_t)tile << 11);
-    st.q = pc->q;
+    st.q = pc.q;
     st.inv = a.inv_last[i];
     st.accumulate = a.accumulate;
     st.splits = a.acc_splits;
     st.split_stride = a.acc_split_stride >> 1;
-    fwd_contig_tile<LOGN, NOGUARD, StoreModDown>(a.u + (((size_t)p * a.Lout + i) << LOGN), tile, a.tw + ((size_t)i << LOGN), pc->q,
-                                                 pc->q2, lds2, threadIdx.x, a.twb + (size_t)i * ((size_t)TPR * 15 * 256),
-                                                 pc->cr1, st);
+    // the tile hands the store canonical integers in every mode
+    fwd_contig_tile<LOGN, MODE, StoreModDown>(a.u + (((size_t)p * a.Lout + i) << LOGN), tile, a.tw + ((size_t)i << LOGN), mode_q<MODE>(pc),
+                                              mode_q2<MODE>(pc), lds2, threadIdx.x, a.twb + (size_t)i * ((size_t)TPR * 15 * 256), pc.cr1,
+                                              st);
 }
 
 } // namespace moai

@@ -21,8 +21,10 @@ def ks_arith(request, moai):
     """Key-switch tests run twice: with the FP64 arithmetic modes forced on for every prime below 2^51 (the
     library only picks them from 16 digit rows per call) and with the integer units only."""
     moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 0 if request.param == "fp64" else 1 << 40)
+    moai.hip.set_tuning("MOAI_MD_FP_MIN_ROWS", 0 if request.param == "fp64" else 1 << 40)  # the mod-down tail and rescale
     yield request.param
     moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 16)
+    moai.hip.set_tuning("MOAI_MD_FP_MIN_ROWS", 256)
 
 
 @pytest.fixture(scope="module")
@@ -209,7 +211,7 @@ def test_ct_pt_dot_matches_multiply_plain_add_chain(moai, terms, bits):
 
 
 @pytest.mark.parametrize("L", [5, 4, 2])
-def test_rescale_and_drop(moai, env12, L):
+def test_rescale_and_drop(moai, env12, L, ks_arith):
     logn, primes, octx, ctx = env12
     n = 1 << logn
     rng = np.random.default_rng(5 + L)
@@ -554,6 +556,7 @@ def test_fp64_modes_at_their_size_limits(moai):
     k = len(primes)
     rng = np.random.default_rng(77)
     moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 0)
+    moai.hip.set_tuning("MOAI_MD_FP_MIN_ROWS", 0)
     try:
         # forward NTT: canonical extremes and lazy inputs up to 4q - 1
         x = O.uniform_rns(rng, primes, (3,), n)
@@ -587,5 +590,22 @@ def test_fp64_modes_at_their_size_limits(moai):
             got = dct.to_numpy(ct.shape)
             for b in range(2):
                 assert (got[b] == octx.switch_key(ct[b], tgt[b], key, L).reshape(2, L, n)).all(), (trial, b)
+        # rescale (the mod-down tail under the FP64 modes): every level of this chain, the dropped row's
+        # coefficients at 0, q_last - 1 and around q_last / 2 (the rounding boundary), the kept rows at q - 1
+        for L in range(k, 1, -1):
+            x = O.uniform_rns(rng, primes[:L], (3, 2), n)
+            ql = primes[L - 1]
+            pattern = np.array([0, ql - 1, ql // 2, ql // 2 + 1, ql // 2 - 1, 1], dtype=np.uint64)
+            coeff = np.resize(pattern, n)
+            x[0, :, L - 1, :] = octx.ntt(coeff, 1, prime_index=[L - 1]).reshape(n)  # NTT form of that coefficient row
+            for i in range(L - 1):
+                x[1, :, i, :] = primes[i] - 1
+            dx = up(moai, x)
+            do = moai.DeviceBuffer(3 * 2 * (L - 1) * n)
+            ctx.rescale(dx, do, 2, L, 3)
+            got = do.to_numpy((3, 2, L - 1, n))
+            for b in range(3):
+                assert (got[b] == octx.rescale(x[b], 2, L)).all(), (L, b)
     finally:
         moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 16)
+        moai.hip.set_tuning("MOAI_MD_FP_MIN_ROWS", 256)

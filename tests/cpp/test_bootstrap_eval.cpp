@@ -303,6 +303,33 @@ int main(int argc, char **argv)
                        context.first_context_data()->chain_index() - context.get_context_data(want.parms_id())->chain_index());
             }
         }
+        // refusals, as in the reference (Bootstrapper.cpp:2939-2945) and for shapes it leaves undefined
+        {
+            auto throws = [&](auto &&f) {
+                try
+                {
+                    f();
+                }
+                catch (const std::invalid_argument &)
+                {
+                    return true;
+                }
+                return false;
+            };
+            Ciphertext top;
+            {
+                Plaintext pl;
+                encoder.encode(0.5, scale, pl);
+                encryptor.encrypt(pl, top);
+            }
+            CHECK(throws([&] { boot.modraise_inplace(top); })); // not at the lowest level
+            Ciphertext out;
+            CHECK(throws([&] { boot.bootstrap_3(out, top); }));
+            CHECK(throws([&] {
+                moai_fused::PackedBootstrapper3 sparse(context, encoder, evaluator, relin_keys, gal_keys, logn - 1, logn, final_scale, dg, reducer);
+            })); // the sparse-slot driver (bootstrap_sparse_3) is not provided
+            CHECK(throws([&] { ChebyshevHeap bad(vector<double>{ 1.0 }); }));
+        }
         // a second pack reuses every cached diagonal set, including the rescaled third one
         Ciphertext packed2 = moai_fused::pack(cts, context), packed_out2;
         boot.bootstrap_3(packed_out2, packed2);

@@ -13,8 +13,9 @@ timeout -k 10 200 ./tools/cpp/bench_shim > $o/bench_shim.txt 2>&1
 timeout -k 10 100 ./tools/valu_bench > $o/valu_bench.txt 2>&1
 timeout -k 10 600 ./tools/cpp/bench_attention 16 768 > $o/attention.txt 2>&1
 timeout -k 10 600 ./tools/cpp/bench_bootstrap_lt 32 16 > $o/bootstrap_lt.txt 2>&1
+timeout -k 10 600 ./tools/cpp/bench_bootstrap 16 16 16 > $o/bootstrap_3.txt 2>&1
 timeout -k 10 900 ./tools/cpp/bench_layer 16 > $o/layer_full.txt 2>&1
 grep -a "LayerNorm\|intermediate\|GELU\|final X\|feed-forward" $o/layer_full.txt | cut -c1-400 > $o/layer.txt
 timeout -k 10 300 ./tools/cpp/bench_streams 15 > $o/streams.txt 2>&1
 tail -3 $o/round_profile.txt | cut -c1-200
-cat $o/op_times.txt $o/ks_time.txt $o/matmul_time.txt $o/encode_time.txt $o/bench_shim.txt $o/attention.txt $o/bootstrap_lt.txt $o/layer.txt $o/streams.txt
+cat $o/op_times.txt $o/ks_time.txt $o/matmul_time.txt $o/encode_time.txt $o/bench_shim.txt $o/attention.txt $o/bootstrap_lt.txt $o/bootstrap_3.txt $o/layer.txt $o/streams.txt

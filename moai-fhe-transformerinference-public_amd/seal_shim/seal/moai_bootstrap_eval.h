@@ -615,7 +615,8 @@ namespace moai_fused
         std::vector<std::vector<std::complex<double>>> fftcoeff1, fftcoeff2, fftcoeff3;          // slot-to-coefficient
     };
 
-    // Bootstrapper::bootstrap_3 for logn == logNh (bootstrap_full_3) on packed ciphertexts
+    // Bootstrapper::bootstrap_3 for logn == logNh (bootstrap_full_3) on packed ciphertexts.  Like the reference's
+    // Bootstrapper it keeps references to the encoder, evaluator and keys: they must outlive it.
     class PackedBootstrapper3
     {
     public:
@@ -623,7 +624,7 @@ namespace moai_fused
                             const seal::RelinKeys &relin_keys, const seal::GaloisKeys &gal_keys, int logn, int logNh,
                             double final_scale, const BootDiagonals3 &diagonals, const ModularReducer3 &mod_reducer)
             : context_(context), encoder_(encoder), evaluator_(evaluator), relin_keys_(relin_keys), gal_keys_(gal_keys), logn_(logn),
-              Nh_(1 << logNh), n_(1 << logn), final_scale_(final_scale), coeff_(diagonals), mod_reducer_(mod_reducer)
+              Nh_(1 << logNh), n_(1 << logn), final_scale_(final_scale), fftcoeff3_(diagonals.fftcoeff3), mod_reducer_(mod_reducer)
         {
             if (logn != logNh)
             {
@@ -719,7 +720,7 @@ namespace moai_fused
                     for (int j = 0; j < n_; j++)
                     {
                         scaled[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)] =
-                            coeff_.fftcoeff3.at(static_cast<std::size_t>(i)).at(static_cast<std::size_t>(j)) * curr_mod * mod_zero * final_scale_ /
+                            fftcoeff3_.at(static_cast<std::size_t>(i)).at(static_cast<std::size_t>(j)) * curr_mod * mod_zero * final_scale_ /
                             (tmpct2.scale() * tmpct2.scale() * initial_scale_);
                     }
                 }
@@ -802,7 +803,7 @@ namespace moai_fused
         const seal::GaloisKeys &gal_keys_;
         int logn_, Nh_, n_;
         double final_scale_, initial_scale_ = 1;
-        BootDiagonals3 coeff_;
+        std::vector<std::vector<std::complex<double>>> fftcoeff3_; // rescaled per running scale in sfl_full_3; the other sets live in their transforms
         ModularReducer3 mod_reducer_;
         std::unique_ptr<BsgsLinearTransform> inv_[3], fwd_[2];
         int fwd_totlen2_ = 0, fwd_totlen3_ = 0, fwd_basicstep3_ = 1;

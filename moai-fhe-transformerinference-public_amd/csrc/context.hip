@@ -486,6 +486,7 @@ int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out)
         if (e != hipSuccess)
         {
             a.ptr = nullptr;
+            (void)hipGetLastError(); // reported through the return value, see moai_malloc
             return set_error(MOAI_ENOMEM, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
         }
         a.bytes = bytes;
@@ -542,6 +543,9 @@ extern "C" int moai_malloc(void **dptr, size_t bytes)
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
     if (e != hipSuccess)
     {
+        // the failure is reported through the return value; do not leave it behind as the thread's "last error",
+        // where the next launch check would find it after the caller has freed memory and retried successfully
+        (void)hipGetLastError();
         return set_error(MOAI_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
     return MOAI_OK;

@@ -416,6 +416,22 @@ def test_config2_shape_properties(moai):
     assert (dx.to_numpy(x.shape) == x).all()
 
 
+def test_failed_allocation_does_not_poison_later_launches(moai, env12):
+    """A refused hipMalloc is reported through the return value only: callers (the shim's block pool) free memory
+    and retry, and the launch checks that follow must not trip over a stale "out of memory"."""
+    import ctypes as C
+
+    logn, primes, octx, ctx = env12
+    p = C.c_void_p()
+    rc = moai.hip.lib().moai_malloc(C.byref(p), C.c_size_t(1 << 46))  # 64 TiB
+    assert rc != 0 and not p.value
+    n = 1 << logn
+    x = O.uniform_rns(np.random.default_rng(3), primes[:2], (1,), n)
+    d = up(moai, x)
+    ctx.ntt_forward(d, 1, 2)
+    assert (d.to_numpy(x.shape) == octx.ntt(x, 2)).all()
+
+
 def test_empty_and_degenerate_calls(moai, env12):
     """zero-sized batches are no-ops; L = 1 (last level) works; invalid levels are refused."""
     logn, primes, octx, ctx = env12

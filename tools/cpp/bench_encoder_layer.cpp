@@ -18,7 +18,7 @@
 // Weights are synthetic N(0, 0.02) (the reference's dense weights are not in the checkout); the bootstrap uses
 // stand-in constants (seal/moai_bootstrap_eval.h), so values lose their meaning after the first bootstrap: this
 // binary measures time, the per-stage correctness checks live in the tests and the per-stage drivers.
-// usage: bench_encoder_layer [heads = 12] [bootstrap packs per round = 48] [gelu packs = 48]
+// usage: bench_encoder_layer [heads = 12] [bootstrap packs per round = all] [gelu packs = 48] [bootstrap pack size = 48]
 //   smaller numbers make a quick plumbing run: the remaining work is skipped and its results are copies.
 #include "seal/seal.h"
 
@@ -191,7 +191,8 @@ static vector<Ciphertext> softmax_boot_packed(const vector<Ciphertext> &enc_X, c
 int main(int argc, char **argv)
 {
     const int heads = argc > 1 ? atoi(argv[1]) : 12;
-    const int boot_packs = argc > 2 ? atoi(argv[2]) : 48;
+    const int boot_B = argc > 4 ? atoi(argv[4]) : 48; // must divide 768; 63.8 ms per bootstrap at 48, 65.6 ms at 16
+    const int boot_packs = argc > 2 ? atoi(argv[2]) : 768 / boot_B;
     const int gelu_packs = argc > 3 ? atoi(argv[3]) : 48;
     omp_set_num_threads(16);
     EncryptionParameters parms(scheme_type::ckks);
@@ -254,9 +255,9 @@ int main(int argc, char **argv)
         moai_fused::chebyshev_interpolant([=](double t) { return cos(two_pi * (25 * t - 0.25) / 4.0); }, 59, 4 * 59), 1 / two_pi, 2);
     moai_fused::PackedBootstrapper3 boot(context, encoder, evaluator, relin_keys, gal_keys_boot, logn, logn, scale, dg, reducer);
 
-    // one bootstrapping round: every ciphertext to the lowest level (:642-646), then bootstrap_3 in packs of 16
+    // one bootstrapping round: every ciphertext to the lowest level (:642-646), then bootstrap_3 in packs of boot_B
     auto bootstrap_round = [&](vector<Ciphertext> &cts, const char *name) {
-        const int B = 16, packs = (int)cts.size() / B;
+        const int B = boot_B, packs = (int)cts.size() / B;
         double t = now_s();
         vector<Ciphertext> out(cts.size());
         for (int pk_i = 0; pk_i < packs; pk_i++)
@@ -283,7 +284,7 @@ int main(int argc, char **argv)
         }
         context.sync();
         t = now_s() - t;
-        fprintf(stderr, "%-28s %8.2f s   (%d of %d packs of 16; chain index -> %zu)\n", name, t, min(packs, boot_packs), packs,
+        fprintf(stderr, "%-28s %8.2f s   (%d of %d packs of %d; chain index -> %zu)\n", name, t, min(packs, boot_packs), packs, B,
                 context.get_context_data(out[0].parms_id())->chain_index());
         cts = std::move(out);
         return t;
@@ -526,7 +527,7 @@ int main(int argc, char **argv)
     t_boot += bootstrap_round(work, "bootstrap round 4");
     context.sync();
     const double total = now_s() - t_layer;
-    const bool full = heads >= 12 && boot_packs >= 48 && gelu_packs >= 48;
+    const bool full = heads >= 12 && boot_packs >= 768 / boot_B && gelu_packs >= 48 && 768 % boot_B == 0;
     fprintf(stderr, "one encoder layer, 256 packed inputs, %s: %.1f s wall (bootstrapping %.1f s = %.0f %%)\n", full ? "complete" : "QUICK RUN (work skipped)", total,
             t_boot, 100 * t_boot / total);
     if (full)

@@ -105,6 +105,7 @@ __device__ __forceinline__ void ct_bfly_noguard(uint64_t &x, uint64_t &y, uint64
 // patterns of (double q, double RN(1/q)).
 enum
 {
+    M_GUARD2 = -1, // integer, any q < 2^61: the guard of every SECOND stage only (values below 8q), plain forward NTT
     M_GUARD = 0,   // integer, reference discipline [0,4q)
     M_NOGUARD = 1, // integer, 36 q < 2^64
     M_FPN = 2,     // FP64, q < 2^52 / 25: sixteen stages need no intermediate reduction
@@ -186,10 +187,34 @@ __device__ __forceinline__ void ct_bfly_fp1(uint64_t &xb, uint64_t &yb, double w
     yb = d2u(u - v);
 }
 
-template <int MODE>
+// Cooley-Tukey butterfly of M_GUARD2.  The reference subtracts 2q from x when x >= 2q in every butterfly to keep
+// values below 4q (dwthandler.h:94-146); the Shoup product accepts any 64-bit y and the sums grow by at most 2q per
+// stage, so for q < 2^61 one guard per TWO stages is enough: an unguarded stage takes values below 6q to below 8q,
+// the next one subtracts 4q when x >= 4q (u < 4q) and is back below 6q.  Residues are unchanged.
+template <bool GUARDED>
+__device__ __forceinline__ void ct_bfly_guard2(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
+{
+#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
+    x += y + w;
+    y ^= wq + q + q2;
+    return;
+#endif
+    uint64_t u = GUARDED ? csub(x, q2 << 1) : x;
+    uint64_t v = mul_shoup_lazy(y, w, wq, q);
+    x = u + v;
+    y = u + q2 - v;
+}
+
+// STAGES_LEFT = number of stages after this one (compile-time in the unrolled tiles): M_GUARD2 guards the stages
+// with an even number left, so the last stage of a transform is guarded and hands over values below 6q
+template <int MODE, int STAGES_LEFT = 0>
 __device__ __forceinline__ void ct_bfly_t(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
-    if (MODE == M_FPN)
+    if (MODE == M_GUARD2)
+    {
+        ct_bfly_guard2<(STAGES_LEFT % 2) == 0>(x, y, w, wq, q, q2);
+    }
+    else if (MODE == M_FPN)
     {
         ct_bfly_fp<false>(x, y, w, wq, q, q2);
     }

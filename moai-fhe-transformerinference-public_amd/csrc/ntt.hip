@@ -62,7 +62,7 @@ static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
         }
         switch (mode)
         {
-        case M_GUARD: launch_fwd_mode<LOGN, M_GUARD>(c, a, s); break;
+        case M_GUARD: launch_fwd_mode<LOGN, M_GUARD2>(c, a, s); break; // same residues, half the guards (modarith.cuh)
         case M_NOGUARD: launch_fwd_mode<LOGN, M_NOGUARD>(c, a, s); break;
         case M_FPN: launch_fwd_mode<LOGN, M_FPN>(c, a, s); break;
         default: launch_fwd_mode<LOGN, M_FPR>(c, a, s); break;

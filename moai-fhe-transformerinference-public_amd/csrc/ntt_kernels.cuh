@@ -132,6 +132,28 @@ struct LoadBarrettFp
     }
 };
 
+
+// the unrolled stage loops of the tiles carry the stage number in a loop variable; M_GUARD2 needs it as a constant
+template <int MODE>
+__device__ __forceinline__ void ct_bfly_stage(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2, int stages_left)
+{
+    if (MODE == M_GUARD2)
+    {
+        if (stages_left & 1)
+        {
+            ct_bfly_guard2<false>(x, y, w, wq, q, q2);
+        }
+        else
+        {
+            ct_bfly_guard2<true>(x, y, w, wq, q, q2);
+        }
+    }
+    else
+    {
+        ct_bfly_t<MODE>(x, y, w, wq, q, q2);
+    }
+}
+
 // one tile of the strided pass: reads row `inp`, writes row `outp` (may be the same row)
 template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD>
 __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
@@ -163,7 +185,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
             if (!(j & half))
             {
                 Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - u);
             }
         }
     }
@@ -194,7 +216,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
                 {
                     uint32_t t_ = (th << 4) | (uint32_t)j;
                     Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
-                    ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
+                    ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - s);
                 }
             }
         }
@@ -217,7 +239,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
 }
 
 template <int LOGN, int MODE = M_GUARD>
-__global__ __launch_bounds__(256, 5) void ntt_fwd_strided(NttArgs a)
+__global__ __launch_bounds__(256, MODE == M_GUARD2 ? 4 : 5) void ntt_fwd_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
@@ -289,7 +311,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             if (!(j & half))
             {
                 Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, 7 - u);
             }
         }
     }
@@ -318,7 +340,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             {
                 // slot = 2^(u-4) - 1 + (j >> (8-u)); consecutive threads read consecutive entries
                 Tw t = twbt[(((1u << (u - 4)) - 1u + (uint32_t)(j >> (8 - u))) << 8) + tid];
-                ct_bfly_t<MODE>(x[j], x[j + half], t.w, t.wq, q, q2);
+                ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, 7 - u);
             }
         }
     }
@@ -336,6 +358,12 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
         {
             v.x = barrett64(x[2 * c], q, cr1);
             v.y = barrett64(x[2 * c + 1], q, cr1);
+        }
+        else if (MODE == M_GUARD2)
+        {
+            // the last stage is a guarded one: values below 6q
+            v.x = csub(csub(csub(x[2 * c], q2 << 1), q2), q);
+            v.y = csub(csub(csub(x[2 * c + 1], q2 << 1), q2), q);
         }
         else
         {

@@ -416,6 +416,32 @@ def test_config2_shape_properties(moai):
     assert (dx.to_numpy(x.shape) == x).all()
 
 
+@pytest.mark.parametrize("logn", [12, 13, 15, 16])
+def test_forward_ntt_guard_every_second_stage(moai, logn):
+    """59..61-bit primes take the integer butterflies with one guard per two stages (modarith.cuh M_GUARD2, values up
+    to 8q < 2^64): canonical extremes and lazy inputs up to 4q - 1, the documented input range, against the oracle."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, [61, 61, 60, 59])
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k = len(primes)
+    rng = np.random.default_rng(100 + logn)
+    x = O.uniform_rns(rng, primes, (4,), n)
+    for i, q in enumerate(primes):
+        x[0, i, :] = q - 1
+        x[1, i, ::2] = 0
+        x[1, i, 1::2] = q - 1
+    want = octx.ntt(x, k)
+    d = up(moai, x)
+    ctx.ntt_forward(d, 4, k)
+    assert (d.to_numpy(x.shape) == want).all()
+    lazy = x.copy()
+    for i, q in enumerate(primes):
+        lazy[:, i, :] += np.uint64(3 * q)  # [3q, 4q): 61-bit primes keep this below 2^63
+    d = up(moai, lazy)
+    ctx.ntt_forward(d, 4, k)
+    assert (d.to_numpy(x.shape) == want).all()
+
+
 def test_failed_allocation_does_not_poison_later_launches(moai, env12):
     """A refused hipMalloc is reported through the return value only: callers (the shim's block pool) free memory
     and retry, and the launch checks that follow must not trip over a stale "out of memory"."""

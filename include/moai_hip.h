@@ -202,6 +202,11 @@ int moai_relinearize(moai_ctx *ctx, const uint64_t *ct3, const uint64_t *relin_k
  * with the key present, rotate_internal :2667-2697): ct: [batch][2][L][N] in place. */
 int moai_apply_galois(moai_ctx *ctx, uint64_t *ct, size_t L, uint32_t galois_elt, const uint64_t *galois_key,
                       size_t batch, void *stream);
+/* The same with a separate destination (Evaluator::apply_galois / rotate_vector / complex_conjugate with a
+ * `destination`, SEAL/evaluator.h:1093-1101, 1191-1227, 1262-1270: "destination = encrypted; ..._inplace(destination)"
+ * without the deep copy): in, out: [batch][2][L][N]; out may be in. */
+int moai_apply_galois_to(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t L, uint32_t galois_elt,
+                         const uint64_t *galois_key, size_t batch, void *stream);
 
 /* ---- MOAI-owned integer kernel ---------------------------------------------------------------------------
  * Bootstrapper::modraise_inplace include/source/bootstrapping/Bootstrapper.cpp:2938-2992:

@@ -112,7 +112,9 @@ struct FinalizeArgs
     uint32_t acc_stride;
     uint32_t Lout;
     uint32_t n2;
-    int accumulate;        // out += result (key switch) instead of out = result (rescale)
+    const uint64_t *addend; // see ModDownArgs
+    uint32_t addend_bstride;
+    int add_mode;
 };
 
 // (acc_i - u_i) * q_last^-1 mod q_i      (rns.cpp:892-897 / evaluator.cpp:3012-3017)
@@ -130,9 +132,10 @@ __global__ __launch_bounds__(256) void moddown_finalize_kernel(FinalizeArgs g)
         ulonglong2 x = a[j], y = u[j], r;
         r.x = csub(mul_shoup_lazy(x.x + q - y.x, inv.w, inv.wq, q), q);
         r.y = csub(mul_shoup_lazy(x.y + q - y.y, inv.w, inv.wq, q), q);
-        if (g.accumulate)
+        if (g.add_mode == 1 || (g.add_mode == 2 && !(p & 1u)))
         {
-            ulonglong2 c = o[j];
+            ulonglong2 c = (reinterpret_cast<const ulonglong2 *>(g.addend) +
+                            ((size_t)(p >> 1) * g.addend_bstride + (size_t)(p & 1u) * g.Lout + i) * g.n2)[j];
             r.x = csub(r.x + c.x, q);
             r.y = csub(r.y + c.y, q);
         }
@@ -265,9 +268,10 @@ static inline size_t align256(size_t x)
 // whose NTT-form row is `last_rows` ([P][N], overwritten), rounding to nearest.
 //   acc row (p, i) = acc + (p * acc_stride + i) * N ; out [P][Lout][N]
 // scratch: u [P][Lout][N]
+//   addend / addend_bstride / add_mode: what is added to the quotient (ModDownArgs); add_mode 0 for rescale
 static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32_t acc_stride, uint64_t *u,
-                   uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, bool accumulate, hipStream_t s,
-                   uint32_t acc_splits = 1, size_t acc_split_stride = 0)
+                   uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, const uint64_t *addend, uint32_t addend_bstride,
+                   int add_mode, hipStream_t s, uint32_t acc_splits = 1, size_t acc_split_stride = 0)
 {
     RowMap rm;
     uint32_t pl = prime_last;
@@ -297,7 +301,9 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
         a.acc_stride = acc_stride;
         a.Lout = (uint32_t)Lout;
         a.P = (uint32_t)P;
-        a.accumulate = accumulate ? 1 : 0;
+        a.addend = addend;
+        a.addend_bstride = addend_bstride;
+        a.add_mode = add_mode;
         a.acc_splits = acc_splits;
         a.acc_split_stride = acc_split_stride;
         // one pair of launches per arithmetic mode present among the output moduli (ntt_mode); below
@@ -382,7 +388,9 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
     f.acc_stride = acc_stride;
     f.Lout = (uint32_t)Lout;
     f.n2 = (uint32_t)(c->n >> 1);
-    f.accumulate = accumulate ? 1 : 0;
+    f.addend = addend;
+    f.addend_bstride = addend_bstride;
+    f.add_mode = add_mode;
     hipLaunchKernelGGL(moddown_finalize_kernel, rgrid(c, P * Lout), dim3(256), 0, s, f);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
@@ -560,9 +568,10 @@ static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const u
 
 // target row block of ciphertext b starts at target + (b * target_stride_rows + target_off_rows) * N.
 // wsp: switch_key_ws_bytes() bytes of scratch.
+// ct [batch][2][L][N] = addend (add_mode, ModDownArgs) + key switch of `target`; ct may be the addend itself
 static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, size_t target_stride_rows,
                            size_t target_off_rows, const uint64_t *key, size_t L, size_t batch, void *wsp,
-                           hipStream_t s)
+                           hipStream_t s, const uint64_t *addend, size_t addend_bstride, int add_mode)
 {
     const size_t n = c->n;
     const size_t k = c->k;
@@ -708,7 +717,8 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     hipLaunchKernelGGL(sum_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc, last, (uint32_t)(L + 1), (uint32_t)L, splits,
                        split_stride, c->pc, (uint32_t)(k - 1), n2);
     MOAI_LAUNCH_CHECK();
-    return moddown(c, last, acc, (uint32_t)(L + 1), ops, ct, batch * 2, L, (uint32_t)(k - 1), true, s, splits, split_stride);
+    return moddown(c, last, acc, (uint32_t)(L + 1), ops, ct, batch * 2, L, (uint32_t)(k - 1), addend, (uint32_t)addend_bstride, add_mode, s, splits,
+                   split_stride);
 }
 
 } // namespace moai
@@ -753,7 +763,7 @@ extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size
     hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1),
                        NO_ZERO, (uint32_t)(c->n >> 1));
     MOAI_LAUNCH_CHECK();
-    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), false, s);
+    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), nullptr, 0, 0, s);
 }
 
 extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,
@@ -779,7 +789,7 @@ extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target
     {
         return rc;
     }
-    return switch_key_impl(c, ct, target, L, 0, key, L, batch, wsp, (hipStream_t)stream);
+    return switch_key_impl(c, ct, target, L, 0, key, L, batch, wsp, (hipStream_t)stream, ct, 2 * L, 1);
 }
 
 extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t *relin_key, uint64_t *out, size_t L,
@@ -806,15 +816,13 @@ extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t
     {
         return rc;
     }
-    // out = (c0, c1); out += switch_key(c2, relin_keys[0])      (evaluator.cpp:1383-1392)
-    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2 * L), dim3(256), 0, s, ct3, out, (uint32_t)(2 * L),
-                       (uint32_t)(3 * L), 0u, NO_ZERO, (uint32_t)(c->n >> 1));
-    MOAI_LAUNCH_CHECK();
-    return switch_key_impl(c, out, ct3, 3 * L, 2 * L, relin_key, L, batch, wsp, s);
+    // out = (c0, c1) + switch_key(c2, relin_keys[0])      (evaluator.cpp:1383-1392): c0 and c1 are read from ct3 by
+    // the last kernel of the key switch, no copy first
+    return switch_key_impl(c, out, ct3, 3 * L, 2 * L, relin_key, L, batch, wsp, s, ct3, 3 * L, 1);
 }
 
-extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t galois_elt, const uint64_t *galois_key,
-                                 size_t batch, void *stream)
+extern "C" int moai_apply_galois_to(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L, uint32_t galois_elt,
+                                    const uint64_t *galois_key, size_t batch, void *stream)
 {
     int rc = check_level(c, L, batch * 2);
     if (rc)
@@ -825,7 +833,7 @@ extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t g
     {
         return MOAI_OK;
     }
-    if (!ct || !galois_key)
+    if (!in || !out || !galois_key)
     {
         return set_error(MOAI_EINVAL, "null argument");
     }
@@ -841,16 +849,20 @@ extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t g
     }
     uint64_t *tmp = static_cast<uint64_t *>(wsp);
     void *ks_ws = static_cast<char *>(wsp) + sz_tmp;
-    // tmp = galois(ct) for both polynomials; ct = (tmp0, 0); ct += switch_key(tmp1)  (evaluator.cpp:2631-2654)
-    rc = moai_galois_permute(c, ct, tmp, batch * 2, L, galois_elt, stream);
+    // tmp = galois(in) for both polynomials; out = (tmp0, 0) + switch_key(tmp1)  (evaluator.cpp:2631-2654): tmp0 is
+    // added by the last kernel of the key switch, so `out` is written once and may be `in`
+    rc = moai_galois_permute(c, in, tmp, batch * 2, L, galois_elt, stream);
     if (rc)
     {
         return rc;
     }
-    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * 2 * L), dim3(256), 0, s, tmp, ct, (uint32_t)(2 * L),
-                       (uint32_t)(2 * L), 0u, (uint32_t)L, (uint32_t)(c->n >> 1));
-    MOAI_LAUNCH_CHECK();
-    return switch_key_impl(c, ct, tmp, 2 * L, L, galois_key, L, batch, ks_ws, s);
+    return switch_key_impl(c, out, tmp, 2 * L, L, galois_key, L, batch, ks_ws, s, tmp, 2 * L, 2);
+}
+
+extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t galois_elt, const uint64_t *galois_key,
+                                 size_t batch, void *stream)
+{
+    return moai_apply_galois_to(c, ct, ct, L, galois_elt, galois_key, batch, stream);
 }
 
 extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream)

@@ -447,9 +447,9 @@ struct StoreModDown
 {
     const ulonglong2 *acc; // tile base of the row being divided (first of `splits` partial copies)
     ulonglong2 *out;       // tile base of the result row
+    const ulonglong2 *add; // tile base of the row to add to the result (key switch), or nullptr (rescale)
     uint64_t q;
     Tw inv;
-    int accumulate;
     uint32_t splits;       // partial sums to add up (key switch on few ciphertexts), 1 otherwise
     size_t split_stride;   // 16-byte chunks between consecutive partial copies
     __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 u) const
@@ -463,9 +463,9 @@ struct StoreModDown
         }
         r.x = csub(mul_shoup_lazy(x.x + q - u.x, inv.w, inv.wq, q), q);
         r.y = csub(mul_shoup_lazy(x.y + q - u.y, inv.w, inv.wq, q), q);
-        if (accumulate)
+        if (add)
         {
-            ulonglong2 c = out[ch];
+            ulonglong2 c = add[ch];
             r.x = csub(r.x + c.x, q);
             r.y = csub(r.y + c.y, q);
         }
@@ -487,7 +487,13 @@ struct ModDownArgs
     uint32_t acc_stride;
     uint32_t Lout;
     uint32_t P;
-    int accumulate;
+    // what is added to the result (the key switch adds its output to a ciphertext, evaluator.cpp:3012-3017):
+    // row (p, i) of the addend is at addend + ((p / 2) * addend_bstride + (p % 2) * Lout + i) * N, i.e. the first two
+    // polynomials of ciphertexts stored addend_bstride rows apart; add_mode 0: nothing, 1: every polynomial,
+    // 2: even polynomials only (apply_galois: c0 gets the permuted c0, c1 starts from zero)
+    const uint64_t *addend;
+    uint32_t addend_bstride;
+    int add_mode;
     uint32_t acc_splits;     // >= 1
     size_t acc_split_stride; // words between partial copies of acc
     uint32_t total_work;
@@ -552,7 +558,12 @@ __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
     st.out = reinterpret_cast<ulonglong2 *>(a.out + (((size_t)p * a.Lout + i) << LOGN)) + ((size_t)tile << 11);
     st.q = pc.q;
     st.inv = a.inv_last[i];
-    st.accumulate = a.accumulate;
+    st.add = nullptr;
+    if (a.add_mode == 1 || (a.add_mode == 2 && !(p & 1u)))
+    {
+        st.add = reinterpret_cast<const ulonglong2 *>(a.addend + (((size_t)(p >> 1) * a.addend_bstride + (size_t)(p & 1u) * a.Lout + i) << LOGN)) +
+                 ((size_t)tile << 11);
+    }
     st.splits = a.acc_splits;
     st.split_stride = a.acc_split_stride >> 1;
     // the tile hands the store canonical integers in every mode

@@ -57,6 +57,7 @@ SYMBOLS = {
     "moai_switch_key": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_relinearize": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_apply_galois": (C.c_int, [vp, vp, sz, C.c_uint32, vp, sz, vp]),
+    "moai_apply_galois_to": (C.c_int, [vp, vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_modraise": (C.c_int, [vp, vp, vp, sz, sz, vp]),
     "moai_ckks_encode": (C.c_int, [vp, vp, C.c_int, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
     "moai_ckks_encode_masked": (C.c_int, [vp, vp, vp, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
@@ -268,6 +269,9 @@ class Context:
 
     def apply_galois(self, ct, L, elt, key, batch, stream=None):
         _check(lib().moai_apply_galois(self.h, _ptr(ct), L, int(elt), _ptr(key), batch, stream))
+
+    def apply_galois_to(self, src, dst, L, elt, key, batch, stream=None):
+        _check(lib().moai_apply_galois_to(self.h, _ptr(src), _ptr(dst), L, int(elt), _ptr(key), batch, stream))
 
     def modraise(self, src, out, L_out, batch, stream=None):
         _check(lib().moai_modraise(self.h, _ptr(src), _ptr(out), L_out, batch, stream))

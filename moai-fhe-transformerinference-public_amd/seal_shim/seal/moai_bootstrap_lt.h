@@ -274,8 +274,7 @@ namespace moai_fused
                     continue;
                 }
                 std::uint64_t *dst = babies.get() + k * batch_words;
-                util::hip_check(moai_memcpy_d2d(dst, src, batch_words * 8, st));
-                rotate_batch(dst, baby_steps_[k], L, B, gal_keys, seq);
+                rotate_batch_from(src, dst, baby_steps_[k], L, B, gal_keys, seq);
             }
             util::DeviceArray acc(batch_words, st), giant(batch_words, st);
             bool first = true;
@@ -323,6 +322,25 @@ namespace moai_fused
             }
             diagonals_.insert(diagonals_.end(), rotated.begin(), rotated.end());
             return static_cast<std::uint32_t>(diagonals_.size() / static_cast<std::size_t>(Nh_) - 1);
+        }
+
+        // the same from `src` into `dst`: the first key switch reads the source, the rest work in place
+        void rotate_batch_from(const std::uint64_t *src, std::uint64_t *dst, int step, std::size_t L, std::size_t B,
+                               const seal::GaloisKeys &keys, std::vector<std::uint32_t> &seq) const
+        {
+            seq.clear();
+            detail::rotation_sequence(context_, keys, step, seq);
+            if (seq.empty())
+            {
+                seal::util::hip_check(moai_memcpy_d2d(dst, src, B * 2 * L * context_.n() * 8, context_.stream()));
+                return;
+            }
+            for (std::size_t h = 0; h < seq.size(); h++)
+            {
+                const std::uint32_t elt = seq[h];
+                seal::util::hip_check(moai_apply_galois_to(context_.device(), h == 0 ? src : dst, dst, L, elt,
+                                                           keys.device_key(seal::GaloisKeys::get_index(elt)), B, context_.stream()));
+            }
         }
 
         // rotate_vector's key switches (Evaluator::rotate_internal) on a whole batch in place

@@ -507,62 +507,13 @@ namespace seal
         void apply_galois_inplace(Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
                                   MemoryPoolHandle = MemoryPoolHandle()) const
         {
-            // SEAL/evaluator.cpp:2563-2665
-            check_ct(encrypted, "encrypted");
-            if (galois_keys.parms_id() != context_.key_parms_id())
-            {
-                throw std::invalid_argument("galois_keys is not valid for encryption parameters");
-            }
-            if (!(galois_elt & 1) || galois_elt >= 2 * context_.n())
-            {
-                throw std::invalid_argument("Galois element is not valid");
-            }
-            if (encrypted.size() > 2)
-            {
-                throw std::invalid_argument("encrypted size must be 2");
-            }
-            if (!galois_keys.has_key(galois_elt))
-            {
-                throw std::invalid_argument("Galois key not present");
-            }
-            if (!encrypted.is_ntt_form())
-            {
-                throw std::invalid_argument("CKKS encrypted must be in NTT form");
-            }
-            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt));
-            const std::size_t L = encrypted.coeff_modulus_size();
-            util::OpCombiner &comb = util::OpCombiner::instance();
-            if (encrypted.batch() == 1 && comb.enabled())
-            {
-                // concurrent callers with the same element, level and key share one batched key switch
-                const std::size_t words = 2 * L * encrypted.poly_modulus_degree();
-                comb.submit(util::OpCombiner::Key(0, L, galois_elt, key, dev()), { encrypted.device_data(), encrypted.device_data() },
-                            [&](const std::vector<util::OpCombiner::Request> &reqs) {
-                                if (reqs.size() == 1)
-                                {
-                                    hip(moai_apply_galois(dev(), reqs[0].out, L, galois_elt, key, 1, st()));
-                                    return;
-                                }
-                                util::DeviceArray tmp(reqs.size() * words, st());
-                                for (std::size_t i = 0; i < reqs.size(); i++)
-                                {
-                                    hip(moai_memcpy_d2d(tmp.get() + i * words, reqs[i].in, words * 8, st()));
-                                }
-                                hip(moai_apply_galois(dev(), tmp.get(), L, galois_elt, key, reqs.size(), st()));
-                                for (std::size_t i = 0; i < reqs.size(); i++)
-                                {
-                                    hip(moai_memcpy_d2d(reqs[i].out, tmp.get() + i * words, words * 8, st()));
-                                }
-                            });
-                return;
-            }
-            hip(moai_apply_galois(dev(), encrypted.device_data(), L, galois_elt, key, encrypted.batch(), st()));
+            galois_into(encrypted, encrypted, galois_elt, galois_keys);
         }
         void apply_galois(const Ciphertext &encrypted, std::uint32_t galois_elt, const GaloisKeys &galois_keys,
                           Ciphertext &destination, MemoryPoolHandle = MemoryPoolHandle()) const
         {
-            destination = encrypted;
-            apply_galois_inplace(destination, galois_elt, galois_keys);
+            // the reference copies and works in place; the device call takes a separate destination
+            galois_into(encrypted, destination, galois_elt, galois_keys);
         }
         void rotate_vector_inplace(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys,
                                    MemoryPoolHandle = MemoryPoolHandle()) const
@@ -572,6 +523,16 @@ namespace seal
         void rotate_vector(const Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys, Ciphertext &destination,
                            MemoryPoolHandle = MemoryPoolHandle()) const
         {
+            // one key switch with the key present (the common case): straight into the destination
+            std::uint32_t elt = steps != 0 && &destination != &encrypted && context_.get_context_data(encrypted.parms_id()) &&
+                                        galois_keys.parms_id() == context_.key_parms_id()
+                                    ? moai_galois_elt_from_step(dev(), steps)
+                                    : 0;
+            if (elt && galois_keys.has_key(elt))
+            {
+                galois_into(encrypted, destination, elt, galois_keys);
+                return;
+            }
             destination = encrypted;
             rotate_vector_inplace(destination, steps, galois_keys);
         }
@@ -584,8 +545,7 @@ namespace seal
         void complex_conjugate(const Ciphertext &encrypted, const GaloisKeys &galois_keys, Ciphertext &destination,
                                MemoryPoolHandle = MemoryPoolHandle()) const
         {
-            destination = encrypted;
-            complex_conjugate_inplace(destination, galois_keys);
+            galois_into(encrypted, destination, static_cast<std::uint32_t>(2 * context_.n() - 1), galois_keys);
         }
 
         // ---- fork additions (SEAL/evaluator.cpp:395-594) -------------------------------------------------------
@@ -886,6 +846,65 @@ namespace seal
         }
 
         // SEAL/evaluator.cpp:2667-2722
+        // Evaluator::apply_galois_inplace, SEAL/evaluator.cpp:2563-2665, reading `src` and writing `dst` (may be the
+        // same object): no deep copy of the operand first
+        void galois_into(const Ciphertext &src, Ciphertext &dst, std::uint32_t galois_elt, const GaloisKeys &galois_keys) const
+        {
+            check_ct(src, "encrypted");
+            if (galois_keys.parms_id() != context_.key_parms_id())
+            {
+                throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+            }
+            if (!(galois_elt & 1) || galois_elt >= 2 * context_.n())
+            {
+                throw std::invalid_argument("Galois element is not valid");
+            }
+            if (src.size() > 2)
+            {
+                throw std::invalid_argument("encrypted size must be 2");
+            }
+            if (!galois_keys.has_key(galois_elt))
+            {
+                throw std::invalid_argument("Galois key not present");
+            }
+            if (!src.is_ntt_form())
+            {
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            }
+            if (&dst != &src)
+            {
+                like(dst, src);
+            }
+            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt));
+            const std::size_t L = src.coeff_modulus_size();
+            util::OpCombiner &comb = util::OpCombiner::instance();
+            if (src.batch() == 1 && comb.enabled())
+            {
+                // concurrent callers with the same element, level and key share one batched key switch
+                const std::size_t words = 2 * L * src.poly_modulus_degree();
+                comb.submit(util::OpCombiner::Key(0, L, galois_elt, key, dev()), { src.device_data(), dst.device_data() },
+                            [&](const std::vector<util::OpCombiner::Request> &reqs) {
+                                if (reqs.size() == 1)
+                                {
+                                    hip(moai_apply_galois_to(dev(), reqs[0].in, reqs[0].out, L, galois_elt, key, 1, st()));
+                                    return;
+                                }
+                                util::DeviceArray tmp(reqs.size() * words, st());
+                                for (std::size_t i = 0; i < reqs.size(); i++)
+                                {
+                                    hip(moai_memcpy_d2d(tmp.get() + i * words, reqs[i].in, words * 8, st()));
+                                }
+                                hip(moai_apply_galois(dev(), tmp.get(), L, galois_elt, key, reqs.size(), st()));
+                                for (std::size_t i = 0; i < reqs.size(); i++)
+                                {
+                                    hip(moai_memcpy_d2d(reqs[i].out, tmp.get() + i * words, words * 8, st()));
+                                }
+                            });
+                return;
+            }
+            hip(moai_apply_galois_to(dev(), src.device_data(), dst.device_data(), L, galois_elt, key, src.batch(), st()));
+        }
+
         void rotate_internal(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const
         {
             auto cd = context_.get_context_data(encrypted.parms_id());

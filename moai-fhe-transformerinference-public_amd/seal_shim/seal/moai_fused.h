@@ -432,9 +432,8 @@ namespace moai_fused
             {
                 const std::uint64_t *parent = d == 0 ? dW.get() : stack[d - 1].get();
                 stack.emplace_back(cols * ct_words, st);
-                util::hip_check(moai_memcpy_d2d(stack.back().get(), parent, cols * ct_words * 8, st));
                 const std::uint64_t *key = RotK.device_key(GaloisKeys::get_index(want[d]));
-                util::hip_check(moai_apply_galois(dev, stack.back().get(), L, want[d], key, cols, st));
+                util::hip_check(moai_apply_galois_to(dev, parent, stack.back().get(), L, want[d], key, cols, st));
                 current.push_back(want[d]);
             }
             const std::uint64_t *w = want.empty() ? dW.get() : stack.back().get();

@@ -288,6 +288,12 @@ def test_switch_key_relin_galois(moai, env12, L, ks_arith):
         got = dct.to_numpy(ct.shape)
         for b in range(B):
             assert (got[b] == octx.apply_galois(ct[b], L, elt, key).reshape(2, L, n)).all()
+        # separate destination: same result, source untouched
+        dsrc, ddst = up(moai, ct), moai.DeviceBuffer(ct.size)
+        ctx.apply_galois_to(dsrc, ddst, L, elt, dkey, B)
+        assert (ddst.to_numpy(ct.shape) == got).all()
+        assert (dsrc.to_numpy(ct.shape) == ct).all()
+    assert (d3.to_numpy(ct3.shape) == ct3).all()  # relinearize reads c0, c1 in its last kernel and leaves its input alone
 
 
 @pytest.mark.parametrize("bits", [[60, 50, 60, 61], [46, 58, 51, 58]])

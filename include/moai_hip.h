@@ -169,6 +169,12 @@ int moai_ct_pt_matmul(moai_ctx *ctx, const uint64_t *x, const uint64_t *w, uint6
  */
 int moai_rescale(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
                  void *stream);
+/* multiply_plain by a scalar plaintext (moai_mul_scalar_rows) followed by moai_rescale, in one pass over the
+ * ciphertext: Evaluator::multiply_const + rescale_to_next_inplace of the fork (SEAL/evaluator.cpp:395-418,
+ * :1682-1720), the pair the *_reduced_error compositions and MOAI's polynomial evaluations issue for every
+ * coefficient.  Same residues as the two calls.  in: [batch][size][L][N], scalars[L] (host), out: [batch][size][L-1][N]. */
+int moai_mul_scalar_rescale(moai_ctx *ctx, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
+                            size_t L, size_t batch, void *stream);
 /* Evaluator::mod_switch_drop_to_next SEAL/evaluator.cpp:1483-1546 applied `drop` times:
  * in: [batch][size][L][N] -> out: [batch][size][L-drop][N].  out must not alias in (except batch*size == 1,
  * where the kept rows already are in place). */

@@ -271,7 +271,7 @@ static inline size_t align256(size_t x)
 //   addend / addend_bstride / add_mode: what is added to the quotient (ModDownArgs); add_mode 0 for rescale
 static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32_t acc_stride, uint64_t *u,
                    uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, const uint64_t *addend, uint32_t addend_bstride,
-                   int add_mode, hipStream_t s, uint32_t acc_splits = 1, size_t acc_split_stride = 0)
+                   int add_mode, hipStream_t s, uint32_t acc_splits = 1, size_t acc_split_stride = 0, const Tw *scal = nullptr)
 {
     RowMap rm;
     uint32_t pl = prime_last;
@@ -304,6 +304,14 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
         a.addend = addend;
         a.addend_bstride = addend_bstride;
         a.add_mode = add_mode;
+        a.has_scal = scal ? 1 : 0;
+        if (scal)
+        {
+            for (size_t i = 0; i < Lout; ++i)
+            {
+                a.scal[i] = scal[i];
+            }
+        }
         a.acc_splits = acc_splits;
         a.acc_split_stride = acc_split_stride;
         // one pair of launches per arithmetic mode present among the output moduli (ntt_mode); below
@@ -359,6 +367,10 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
         }
         MOAI_LAUNCH_CHECK();
         return MOAI_OK;
+    }
+    if (scal)
+    {
+        return set_error(MOAI_ELOGIC, "fused scalar product needs the tiled transform");
     }
     ExpandLastArgs e;
     e.last = last_rows;
@@ -764,6 +776,88 @@ extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size
                        NO_ZERO, (uint32_t)(c->n >> 1));
     MOAI_LAUNCH_CHECK();
     return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), nullptr, 0, 0, s);
+}
+
+namespace moai {
+// rows[r][:] = rows[r][:] * s mod q, canonical   (the dropped row of a fused scalar product + rescale)
+__global__ __launch_bounds__(256) void scale_rows_kernel(uint64_t *rows, Tw s, uint64_t q, uint32_t n2)
+{
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(rows) + (size_t)blockIdx.y * n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n2; j += gridDim.x * 256u)
+    {
+        ulonglong2 x = d[j];
+        x.x = csub(mul_shoup_lazy(x.x, s.w, s.wq, q), q);
+        x.y = csub(mul_shoup_lazy(x.y, s.w, s.wq, q), q);
+        d[j] = x;
+    }
+}
+} // namespace moai
+
+extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
+                                       size_t L, size_t batch, void *stream)
+{
+    const size_t P = batch * size;
+    int rc = check_level(c, L, P);
+    if (rc)
+    {
+        return rc;
+    }
+    if (L < 2)
+    {
+        return set_error(MOAI_EINVAL, "end of modulus switching chain reached");
+    }
+    if (P == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!in || !out || !scalars || in == out)
+    {
+        return set_error(MOAI_EINVAL, "bad pointers");
+    }
+    if (c->logn < 12)
+    {
+        // small transforms take the two separate steps
+        void *tmp = nullptr;
+        rc = moai_malloc(&tmp, P * L * c->n * sizeof(uint64_t));
+        if (rc)
+        {
+            return rc;
+        }
+        rc = moai_mul_scalar_rows(c, in, scalars, static_cast<uint64_t *>(tmp), P, L, stream);
+        if (!rc)
+        {
+            rc = moai_rescale(c, static_cast<const uint64_t *>(tmp), out, size, L, batch, stream);
+        }
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        moai_free(tmp);
+        return rc ? rc : (e == hipSuccess ? MOAI_OK : set_error(MOAI_EHIP, "%s", hipGetErrorString(e)));
+    }
+    Tw sc[MOAI_MAX_RNS];
+    for (size_t r = 0; r < L; r++)
+    {
+        const uint64_t q = c->primes[r];
+        const uint64_t v = scalars[r] % q; // barrett_reduce_64, polyarithsmallmod.h:209-217
+        sc[r].w = v;
+        sc[r].wq = (uint64_t)((((unsigned __int128)v) << 64) / q);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    const size_t sz_last = align256(P * row_bytes);
+    const size_t sz_u = align256(P * (L - 1) * row_bytes);
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
+    void *wsp;
+    rc = workspace(c, sz_last + sz_u, s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    uint64_t *last = static_cast<uint64_t *>(wsp);
+    uint64_t *u = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_last);
+    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1), NO_ZERO,
+                       (uint32_t)(c->n >> 1));
+    hipLaunchKernelGGL(scale_rows_kernel, rgrid(c, P), dim3(256), 0, s, last, sc[L - 1], c->primes[L - 1], (uint32_t)(c->n >> 1));
+    MOAI_LAUNCH_CHECK();
+    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), nullptr, 0, 0, s, 1, 0, sc);
 }
 
 extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,

@@ -450,6 +450,8 @@ struct StoreModDown
     const ulonglong2 *add; // tile base of the row to add to the result (key switch), or nullptr (rescale)
     uint64_t q;
     Tw inv;
+    Tw sc;                 // use_sc: the divided row is acc * sc mod q (a scalar plaintext product fused into the rescale)
+    int use_sc;
     uint32_t splits;       // partial sums to add up (key switch on few ciphertexts), 1 otherwise
     size_t split_stride;   // 16-byte chunks between consecutive partial copies
     __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 u) const
@@ -460,6 +462,12 @@ struct StoreModDown
             ulonglong2 y = acc[ch + sp * split_stride];
             x.x = csub(x.x + y.x, q);
             x.y = csub(x.y + y.y, q);
+        }
+        if (use_sc)
+        {
+            // multiply_poly_scalar_coeffmod (polyarithsmallmod.cpp:226-278): canonical product, as the separate call gives
+            x.x = csub(mul_shoup_lazy(x.x, sc.w, sc.wq, q), q);
+            x.y = csub(mul_shoup_lazy(x.y, sc.w, sc.wq, q), q);
         }
         r.x = csub(mul_shoup_lazy(x.x + q - u.x, inv.w, inv.wq, q), q);
         r.y = csub(mul_shoup_lazy(x.y + q - u.y, inv.w, inv.wq, q), q);
@@ -499,6 +507,8 @@ struct ModDownArgs
     uint32_t total_work;
     RowMap sel;              // the output rows (= primes) of this launch: one arithmetic mode per launch
     uint32_t Lsel;
+    int has_scal;            // rows of acc are multiplied by scal[i] (reduced scalar + Shoup quotient) before the division
+    Tw scal[MOAI_MAX_RNS];
 };
 
 template <int LOGN, int MODE>
@@ -566,6 +576,8 @@ __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
     }
     st.splits = a.acc_splits;
     st.split_stride = a.acc_split_stride >> 1;
+    st.use_sc = a.has_scal;
+    st.sc = a.scal[i];
     // the tile hands the store canonical integers in every mode
     fwd_contig_tile<LOGN, MODE, StoreModDown>(a.u + (((size_t)p * a.Lout + i) << LOGN), tile, a.tw + ((size_t)i << LOGN), mode_q<MODE>(pc),
                                               mode_q2<MODE>(pc), lds2, threadIdx.x, a.twb + (size_t)i * ((size_t)TPR * 15 * 256), pc.cr1,

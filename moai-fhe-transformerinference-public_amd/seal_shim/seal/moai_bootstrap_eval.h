@@ -10,7 +10,8 @@
 //   ModularReducer::modular_reduction     ModularReducer.cpp:58-78 (the inverse_deg == 1 branch MOAI configures)
 //   Polynomial::generate_poly_heap        common/Polynomial.cpp:168-214, babycount common/func.cpp:120-142
 //   Polynomial::homomorphic_poly_evaluation   common/Polynomial.cpp:255-520
-// Every evaluator call of those routines is issued here in the same order with the same arguments, on a
+// Every evaluator call of those routines is issued here in the same order with the same arguments (a multiply_const
+// that is followed by rescale_to_next_inplace goes out as Evaluator::multiply_const_rescale, one pass, same result), on a
 // ciphertext that carries a whole batch (seal::Ciphertext::batch()), so each call is ONE batched device call;
 // the three transforms of each linear part go through BsgsLinearTransform (cached diagonals).
 //
@@ -225,8 +226,7 @@ namespace moai_fused
             const long d = deg();
             if (d == 1)
             {
-                evaluator.multiply_const(cipher, power_coeff(1), rtn);
-                evaluator.rescale_to_next_inplace(rtn);
+                evaluator.multiply_const_rescale(cipher, power_coeff(1), rtn);
                 evaluator.add_const(rtn, power_coeff(0), rtn);
                 return;
             }
@@ -240,8 +240,7 @@ namespace moai_fused
                 evaluator.rescale_to_next_inplace(squared);
                 if (std::abs(power_coeff(1)) >= zero)
                 {
-                    evaluator.multiply_const(cipher, power_coeff(1), rtn);
-                    evaluator.rescale_to_next_inplace(rtn);
+                    evaluator.multiply_const_rescale(cipher, power_coeff(1), rtn);
                     evaluator.add_reduced_error(rtn, squared, rtn);
                 }
                 else
@@ -257,14 +256,12 @@ namespace moai_fused
                 evaluator.square(cipher, squared);
                 evaluator.relinearize_inplace(squared, relin_keys);
                 evaluator.rescale_to_next_inplace(squared);
-                evaluator.multiply_const(cipher, power_coeff(3), cubic);
-                evaluator.rescale_to_next_inplace(cubic);
+                evaluator.multiply_const_rescale(cipher, power_coeff(3), cubic);
                 evaluator.multiply_inplace_reduced_error(cubic, squared, relin_keys);
                 evaluator.rescale_to_next_inplace(cubic);
                 if (std::abs(power_coeff(1)) >= zero)
                 {
-                    evaluator.multiply_const(cipher, power_coeff(1), rtn);
-                    evaluator.rescale_to_next_inplace(rtn);
+                    evaluator.multiply_const_rescale(cipher, power_coeff(1), rtn);
                     evaluator.add_reduced_error(rtn, cubic, rtn);
                 }
                 else
@@ -357,8 +354,7 @@ namespace moai_fused
                 {
                     auto &h = cipherheap[static_cast<std::size_t>(i)];
                     cipherheapbool[static_cast<std::size_t>(i)] = true;
-                    evaluator.multiply_const(baby[1], node.cheb[1], h);
-                    evaluator.rescale_to_next_inplace(h);
+                    evaluator.multiply_const_rescale(baby[1], node.cheb[1], h);
                     if (!(std::abs(node.cheb[1]) <= zero))
                     {
                         evaluator.add_const_inplace(h, node.cheb[0]);
@@ -371,13 +367,11 @@ namespace moai_fused
                         }
                         if (j < heap_k)
                         {
-                            evaluator.multiply_const(baby[static_cast<std::size_t>(j)], node.cheb[static_cast<std::size_t>(j)], tmp);
-                            evaluator.rescale_to_next_inplace(tmp);
+                            evaluator.multiply_const_rescale(baby[static_cast<std::size_t>(j)], node.cheb[static_cast<std::size_t>(j)], tmp);
                         }
                         else
                         {
-                            evaluator.multiply_const(giant[0], node.cheb[static_cast<std::size_t>(j)], tmp);
-                            evaluator.rescale_to_next_inplace(tmp);
+                            evaluator.multiply_const_rescale(giant[0], node.cheb[static_cast<std::size_t>(j)], tmp);
                         }
                         evaluator.add_reduced_error(h, tmp, h);
                     }

@@ -575,6 +575,52 @@ namespace seal
             mod_switch_to_inplace(const_plain, encrypted.parms_id());
             multiply_plain(encrypted, const_plain, destination);
         }
+        // multiply_const(encrypted, value, destination) followed by rescale_to_next_inplace(destination) as ONE pass
+        // over the ciphertext (moai_mul_scalar_rescale); not part of the reference's interface, same result as the
+        // two calls.  forced_scale > 0 replaces the product's scale before the rescale divides it (the
+        // *_reduced_error compositions overwrite the scale between the two calls, SEAL/evaluator.cpp:447-452).
+        void multiply_const_rescale(const Ciphertext &encrypted, double value, Ciphertext &destination, double forced_scale = 0) const
+        {
+            Plaintext const_plain;
+            encoder_.encode(value, encrypted.scale(), const_plain);
+            mod_switch_to_inplace(const_plain, encrypted.parms_id());
+            // multiply_plain's checks (SEAL/evaluator.cpp:2154-2198, 2336-2373)
+            check_ct(encrypted, "encrypted");
+            if (!const_plain.is_ntt_form() || !encrypted.is_ntt_form())
+            {
+                throw std::invalid_argument("NTT form mismatch");
+            }
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            const double new_scale = encrypted.scale() * const_plain.scale();
+            if (!scale_ok(new_scale, *cd))
+            {
+                throw std::invalid_argument("scale out of bounds");
+            }
+            // rescale_to_next's (SEAL/evaluator.cpp:1682-1720)
+            if (context_.last_parms_id() == encrypted.parms_id())
+            {
+                throw std::invalid_argument("end of modulus switching chain reached");
+            }
+            if (!const_plain.is_scalar())
+            {
+                multiply_plain(encrypted, const_plain, destination);
+                if (forced_scale > 0)
+                {
+                    destination.scale() = forced_scale;
+                }
+                rescale_to_next_inplace(destination);
+                return;
+            }
+            auto next = cd->next_context_data();
+            const std::size_t L = encrypted.coeff_modulus_size();
+            Ciphertext out;
+            out.resize_batch(context_, next->parms_id(), encrypted.size(), encrypted.batch());
+            hip(moai_mul_scalar_rescale(dev(), encrypted.device_data(), const_plain.scalar_rows().data(), out.device_data(), encrypted.size(), L,
+                                        encrypted.batch(), st()));
+            out.is_ntt_form() = true;
+            out.scale() = (forced_scale > 0 ? forced_scale : new_scale) / static_cast<double>(cd->parms().coeff_modulus().back().value());
+            destination = std::move(out);
+        }
         template <typename T>
         void multiply_vector_inplace(Ciphertext &encrypted, const std::vector<T> &value) const
         {
@@ -985,9 +1031,7 @@ namespace seal
                 double q_last = static_cast<double>(cd->parms().coeff_modulus()[c2 - 1].value());
                 Ciphertext adjusted;
                 double scale_adjust = encrypted1.scale() * q_last / (encrypted2.scale() * encrypted2.scale());
-                multiply_const(encrypted2, scale_adjust, adjusted);
-                adjusted.scale() = encrypted1.scale() * q_last;
-                rescale_to_next_inplace(adjusted);
+                multiply_const_rescale(encrypted2, scale_adjust, adjusted, encrypted1.scale() * q_last);
                 mod_switch_to_inplace(adjusted, encrypted1.parms_id());
                 encrypted1.scale() = adjusted.scale();
                 combine(encrypted1, adjusted);
@@ -1002,9 +1046,7 @@ namespace seal
                 double q_last = static_cast<double>(cd->parms().coeff_modulus()[c1 - 1].value());
                 Ciphertext adjusted;
                 double scale_adjust = encrypted2.scale() * q_last / (encrypted1.scale() * encrypted1.scale());
-                multiply_const(encrypted1, scale_adjust, adjusted);
-                adjusted.scale() = encrypted2.scale() * q_last;
-                rescale_to_next_inplace(adjusted);
+                multiply_const_rescale(encrypted1, scale_adjust, adjusted, encrypted2.scale() * q_last);
                 mod_switch_to_inplace(adjusted, encrypted2.parms_id());
                 adjusted.scale() = encrypted2.scale();
                 combine(adjusted, encrypted2);

@@ -160,6 +160,25 @@ int main(int argc, char **argv)
             encoder.encode(x[b], scale, p);
             encryptor.encrypt(p, cts[b]);
         }
+        // the fused multiply_const + rescale the evaluation uses is the two calls, bit for bit (also with the scale
+        // override of the *_reduced_error compositions, and on a pack)
+        {
+            Ciphertext two, one, pk2, pk1;
+            evaluator.multiply_const(cts[0], -0.37, two);
+            evaluator.rescale_to_next_inplace(two);
+            evaluator.multiply_const_rescale(cts[0], -0.37, one);
+            CHECK(one.parms_id() == two.parms_id() && one.scale() == two.scale() && one.download() == two.download());
+            evaluator.multiply_const(cts[1], 1.25e-3, two);
+            two.scale() = scale * 3.0;
+            evaluator.rescale_to_next_inplace(two);
+            evaluator.multiply_const_rescale(cts[1], 1.25e-3, one, scale * 3.0);
+            CHECK(one.scale() == two.scale() && one.download() == two.download());
+            Ciphertext packed = moai_fused::pack(cts, context);
+            evaluator.multiply_const(packed, 0.5, pk2);
+            evaluator.rescale_to_next_inplace(pk2);
+            evaluator.multiply_const_rescale(packed, 0.5, pk1);
+            CHECK(pk1.batch() == pk2.batch() && pk1.download() == pk2.download());
+        }
         vector<Ciphertext> single(B);
         for (int b = 0; b < B; b++) reducer.modular_reduction(evaluator, relin_keys, single[b], cts[b]);
         Ciphertext packed = moai_fused::pack(cts, context), packed_out;

@@ -237,6 +237,40 @@ def test_rescale_and_drop(moai, env12, L, ks_arith):
             ctx.rescale(one, do, size, 1, B)
 
 
+@pytest.mark.parametrize("logn,bits", [(12, [51, 46, 46, 51, 58]), (13, [60, 40, 61, 30]), (10, [50, 40, 45])])
+def test_scalar_product_fused_into_rescale(moai, logn, bits, ks_arith):
+    """moai_mul_scalar_rescale = moai_mul_scalar_rows followed by moai_rescale (multiply_const + rescale_to_next of
+    the fork), residues identical to the two calls and to the oracle; scalars above the modulus are reduced first."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    rng = np.random.default_rng(31 + logn)
+    for L in range(len(primes), 1, -1):
+        B, size = 3, 2
+        x = O.uniform_rns(rng, primes[:L], (B, size), n)
+        scalars = [int(rng.integers(0, 1 << 62)) for _ in range(L)]
+        scalars[0] = primes[0] - 1
+        if L > 2:
+            scalars[1] = 0
+        dx = up(moai, x)
+        dprod = moai.DeviceBuffer(x.size)
+        two = moai.DeviceBuffer(B * size * (L - 1) * n)
+        one = moai.DeviceBuffer(B * size * (L - 1) * n)
+        ctx.mul_scalar_rows(dx, scalars, dprod, B * size, L)
+        ctx.rescale(dprod, two, size, L, B)
+        ctx.mul_scalar_rescale(dx, scalars, one, size, L, B)
+        want = two.to_numpy((B, size, L - 1, n))
+        assert (one.to_numpy((B, size, L - 1, n)) == want).all(), L
+        assert (dx.to_numpy(x.shape) == x).all()
+        # and against the oracle: rescale of the canonical products
+        prod = x.copy()
+        for i in range(L):
+            q = primes[i]
+            prod[:, :, i, :] = (prod[:, :, i, :].astype(object) * (scalars[i] % q) % q).astype(np.uint64)
+        for b in range(B):
+            assert (want[b] == octx.rescale(prod[b], size, L)).all(), (L, b)
+
+
 def test_galois_permute(moai, env12):
     logn, primes, octx, ctx = env12
     n = 1 << logn

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="ciphertexts per GPU (default: the config's 256)")
+    ap.add_argument("--split", action="store_true",
+                    help="strong scaling: divide ONE batch of --batch ciphertexts over the ranks (shard.shard_range) "
+                         "instead of giving every rank its own batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -67,11 +70,16 @@ def main():
     primes = primes_44x60()
     ctx = m.Context(LOGN, primes, device=local_rank)
 
-    B = args.batch
+    # weak scaling (default): every rank owns a whole batch.  --split: the ranks share one batch, each taking the
+    # contiguous range of ciphertexts shard_range gives it (BASELINE.json north_star: "the 256-ciphertext input
+    # batch shards embarrassingly across the 8 GPUs"); still no exchange step.
+    B, first_ct = batch_of_rank(args.batch, rank, world, args.split, m.shard)
+    if B == 0:
+        raise SystemExit("--split with more ranks than ciphertexts leaves rank %d without work" % rank)
     n_poly = B * 2
     # synthetic residues, uniform in [0, q_i) per RNS row, generated on the device
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
+    gen.manual_seed(1 + (first_ct if args.split else rank))
     data = torch.empty((B, 2, L, N), dtype=torch.int64, device=dev)
     for i, q in enumerate(primes):
         data[:, :, i, :] = torch.randint(0, q, (B, 2, N), dtype=torch.int64, device=dev, generator=gen)
@@ -120,7 +128,9 @@ def main():
     coeffs = n_poly * L * N
     bytes_dir = 16.0 * coeffs
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * 2 * bytes_dir / (elapsed / args.steps) / 1e9  # GB/s, whole job
+    # whole job: all ranks' rows over the slowest rank's time (weak: world batches; split: the one batch)
+    job_coeffs = m.shard.sum_over_ranks(float(coeffs), dist, dev)
+    value = 2 * 16.0 * job_coeffs / (elapsed / args.steps) / 1e9  # GB/s
 
     out = {
         "metric": "NTT+INTT algorithmic GB/s (N=2^16, L=44x60-bit, batch=256 ciphertexts/GPU) vs HBM peak",
@@ -131,13 +141,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.split else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: negacyclic NTT then INTT, N=65536, 44 x 60-bit primes, %d ciphertexts x 2 polys per GPU" % B,
+            "workload": "configs[1]: negacyclic NTT then INTT, N=65536, 44 x 60-bit primes, %s" % (
+                "%d ciphertexts x 2 polys split over %d GPUs" % (args.batch, world) if args.split
+                else "%d ciphertexts x 2 polys per GPU" % B),
             "batch_per_gpu": B,
+            "batch_total": args.batch if args.split else B * world,
             "coeff_modulus": "CoeffModulus::Create(65536, 44 x 60)",
             "bytes_per_coeff_per_transform": 16,
         },
@@ -164,6 +177,14 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def batch_of_rank(batch, rank, world, split, shard):
+    """(ciphertexts this rank transforms, index of its first one in the job's batch)"""
+    if not split:
+        return batch, rank * batch
+    start, count = shard.shard_range(batch, rank, world)
+    return count, start
 
 
 def primes_44x60():

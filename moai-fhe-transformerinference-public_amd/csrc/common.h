@@ -29,7 +29,7 @@ struct alignas(16) PrimeConst
     uint64_t cr1;      //                   high word
     Tw ninv;           // N^-1 mod q                     (NTTTables::inv_degree_modulo, ntt.cpp:290-296)
     Tw ninv_w1;        // N^-1 * inv_tw[1] mod q: last inverse stage with the scaling folded in
-    uint64_t qd;       // bit pattern of (double) q          } FP64 arithmetic modes (modarith.cuh),
+    uint64_t qd;       // bit pattern of (double) q          } FP64 arithmetic modes (modarith.hip.h),
     uint64_t qinv;     // bit pattern of RN(1.0 / q)         } meaningful when fp_mode != 0
     uint64_t fp_mode;  // 0: integer only; M_FPN or M_FPR
     uint64_t pad[5];
@@ -56,6 +56,16 @@ int set_error(int code, const char *fmt, ...);
 
 #define MOAI_LAUNCH_CHECK() MOAI_HIP_CHECK(hipGetLastError())
 
+// row-per-block launches put the row count in gridDim.y, which HIP limits to 65535
+#define MOAI_CHECK_GRID_ROWS(rows)                                                                                   \
+    do                                                                                                               \
+    {                                                                                                                \
+        if ((size_t)(rows) > 65535u)                                                                                 \
+        {                                                                                                            \
+            return ::moai::set_error(MOAI_EINVAL, "batch too large for one launch: %zu rows (limit 65535)", (size_t)(rows)); \
+        }                                                                                                            \
+    } while (0)
+
 } // namespace moai
 
 // The opaque context of the C ABI.
@@ -80,7 +90,7 @@ struct moai_ctx
     moai::Tw *fwd_twf = nullptr;
     moai::Tw *fwd_twfb = nullptr;
     // the same powers as plain doubles, 8 bytes per entry (fwd_tw indexing): the contiguous key-switch kernel is
-    // bound by twiddle fetches and takes its quotient estimate from RN(1/q) instead (modarith.cuh ct_bfly_fp1)
+    // bound by twiddle fetches and takes its quotient estimate from RN(1/q) instead (modarith.hip.h ct_bfly_fp1)
     double *fwd_twf1 = nullptr;
     moai::PrimeConst *pc = nullptr;    // [k]
     // inv_q_last_mod_q[l][i] = q_l^-1 mod q_i as Shoup operands, l in [1,k), i < l  (rns.cpp:769-775)

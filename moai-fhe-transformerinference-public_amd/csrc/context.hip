@@ -33,6 +33,12 @@ const char *last_error()
 static std::mutex g_tuning_mu;
 static std::map<std::string, long> g_tuning;
 
+int enter_device(const moai_ctx *c)
+{
+    MOAI_HIP_CHECK(hipSetDevice(c->device));
+    return MOAI_OK;
+}
+
 long tuning(const char *name, long dflt)
 {
     {
@@ -197,7 +203,7 @@ static void build_prime(int logn, uint64_t q, uint64_t psi, Tw *fwd, Tw *inv, Pr
         pc->cr0 = q0;
         pc->cr1 = q1;
     }
-    // FP64 arithmetic modes (modarith.cuh): q < 2^51; without intermediate reductions when sixteen stages
+    // FP64 arithmetic modes (modarith.hip.h): q < 2^51; without intermediate reductions when sixteen stages
     // starting from |x| <= q/2 and growing by at most 2 q each (the w-only butterfly, ct_bfly_fp1) stay below 2^52
     if (q < (1ull << 51))
     {
@@ -329,7 +335,7 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         moai_ctx_destroy(c);
         return set_error(MOAI_EINVAL, "invalid modulus: no primitive 2N-th root");
     }
-    // per-thread ordering of the contiguous pass's last four stages (ntt_kernels.cuh fwd_contig_tile)
+    // per-thread ordering of the contiguous pass's last four stages (ntt_kernels.hip.h fwd_contig_tile)
     std::vector<Tw> fwdb, invb;
     const size_t nb = logn >= 12 ? (n >> 12) * 15 * 256 : 0;
     if (nb)
@@ -359,7 +365,7 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
             }
         }
     }
-    // FP64 forward tables: {double w, double RN(w / q)} in the two words of a Tw (modarith.cuh)
+    // FP64 forward tables: {double w, double RN(w / q)} in the two words of a Tw (modarith.hip.h)
     std::vector<Tw> fwdf, fwdfb;
     std::vector<double> fwdf1;
     if (logn >= 12)
@@ -469,11 +475,44 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
 
 namespace moai {
 // grow the arena of `stream` to at least `bytes`; synchronises the device when it has to reallocate
-int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out)
+static int reserve_for_stream_locked(moai_ctx *c, moai_ctx::Arena &a, size_t bytes);
+int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out, bool headroom)
 {
     std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
     moai_ctx::Arena &a = c->ws[stream];
     if (bytes > a.bytes)
+    {
+        if (headroom)
+        {
+            // an operation outgrew the arena: over-allocate so that a slowly growing batch or level mix does not pay a
+            // device synchronisation plus a multi-GiB hipFree / hipMalloc on every call (falls back to the exact size)
+            const size_t want = bytes + bytes / 4 > a.bytes + a.bytes / 2 ? bytes + bytes / 4 : a.bytes + a.bytes / 2;
+            int rc = reserve_for_stream_locked(c, a, want);
+            if (rc == MOAI_OK)
+            {
+                if (out)
+                {
+                    *out = a.ptr;
+                }
+                return MOAI_OK;
+            }
+        }
+        int rc = reserve_for_stream_locked(c, a, bytes);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    if (out)
+    {
+        *out = a.ptr;
+    }
+    return MOAI_OK;
+}
+
+int reserve_for_stream_locked(moai_ctx *c, moai_ctx::Arena &a, size_t bytes)
+{
+    (void)c;
     {
         MOAI_HIP_CHECK(hipDeviceSynchronize());
         if (a.ptr)
@@ -491,10 +530,6 @@ int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out)
         }
         a.bytes = bytes;
     }
-    if (out)
-    {
-        *out = a.ptr;
-    }
     return MOAI_OK;
 }
 } // namespace moai
@@ -506,7 +541,7 @@ extern "C" int moai_ctx_reserve(moai_ctx *c, size_t bytes)
         return set_error(MOAI_EINVAL, "null context");
     }
     // reserves the arena of the default stream; other streams grow theirs on first use
-    return moai::reserve_for_stream(c, nullptr, bytes, nullptr);
+    return moai::reserve_for_stream(c, nullptr, bytes, nullptr, false);
 }
 
 extern "C" int moai_ctx_reserve_stream(moai_ctx *c, void *stream, size_t bytes)
@@ -515,7 +550,7 @@ extern "C" int moai_ctx_reserve_stream(moai_ctx *c, void *stream, size_t bytes)
     {
         return set_error(MOAI_EINVAL, "null context");
     }
-    return moai::reserve_for_stream(c, stream, bytes, nullptr);
+    return moai::reserve_for_stream(c, stream, bytes, nullptr, false);
 }
 
 extern "C" size_t moai_ctx_coeff_count(const moai_ctx *c)
@@ -607,7 +642,15 @@ extern "C" int moai_device_info(int device, char *name, size_t cap, int *cus, si
     MOAI_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     if (name && cap)
     {
-        snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+        // some ROCm builds leave prop.name empty for this part: describe the device by what the runtime does report
+        if (prop.name[0])
+        {
+            snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+        }
+        else
+        {
+            snprintf(name, cap, "%s, %d CUs, %zu GiB", prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem >> 30);
+        }
     }
     if (cus)
     {

@@ -8,7 +8,7 @@
 #include <mutex>
 
 #include "launch.h"
-#include "modarith.cuh"
+#include "modarith.hip.h"
 
 namespace moai {
 
@@ -457,7 +457,7 @@ static int check_rows(const moai_ctx *c, size_t n_poly, size_t L)
     {
         return set_error(MOAI_EINVAL, "batch too large for one launch");
     }
-    return MOAI_OK;
+    return enter_device(c);
 }
 
 int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out)
@@ -485,14 +485,11 @@ int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out)
 
 int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out)
 {
-    // per-stream arena; a first-time or larger request reallocates (with 25% headroom), which
-    // synchronises the device and therefore must not happen under stream capture
+    // per-stream arena; a first-time or larger request reallocates with headroom (max of 1.25 x the request and
+    // 1.5 x the old size), which synchronises the device and therefore must not happen under stream capture
+    // (moai_ctx_reserve[_stream] sizes the arena beforehand)
     void *p = nullptr;
-    int rc = reserve_for_stream(c, (void *)s, bytes, &p);
-    if (rc == MOAI_OK && !p)
-    {
-        rc = reserve_for_stream(c, (void *)s, bytes + bytes / 4, &p);
-    }
+    int rc = reserve_for_stream(c, (void *)s, bytes ? bytes : 256, &p, true);
     if (rc)
     {
         return rc;
@@ -526,6 +523,7 @@ static int ew_launch(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t
     g.L = (uint32_t)L;
     g.n2 = (uint32_t)(c->n >> 1);
     g.b_rows = (uint32_t)(n_poly_b * L);
+    MOAI_CHECK_GRID_ROWS(n_poly * L);
     hipLaunchKernelGGL(ew_kernel<OP>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
@@ -593,10 +591,12 @@ static int scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, 
     }
     if (mul)
     {
+        MOAI_CHECK_GRID_ROWS(n_poly * L);
         hipLaunchKernelGGL(scalar_rows_kernel<true>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
     }
     else
     {
+        MOAI_CHECK_GRID_ROWS(n_poly * L);
         hipLaunchKernelGGL(scalar_rows_kernel<false>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
     }
     MOAI_LAUNCH_CHECK();
@@ -644,10 +644,12 @@ static int ct_mul(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *o
     g.n2 = (uint32_t)(c->n >> 1);
     if (square)
     {
+        MOAI_CHECK_GRID_ROWS(batch * L);
         hipLaunchKernelGGL(ct_mul_kernel<true>, row_grid(c, batch * L), dim3(256), 0, (hipStream_t)stream, g);
     }
     else
     {
+        MOAI_CHECK_GRID_ROWS(batch * L);
         hipLaunchKernelGGL(ct_mul_kernel<false>, row_grid(c, batch * L), dim3(256), 0, (hipStream_t)stream, g);
     }
     MOAI_LAUNCH_CHECK();
@@ -696,6 +698,7 @@ extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, ui
     g.count = (uint32_t)count;
     g.L = (uint32_t)L;
     g.n2 = (uint32_t)(c->n >> 1);
+    MOAI_CHECK_GRID_ROWS(L);
     hipLaunchKernelGGL(ct_dot_kernel, row_grid(c, L), dim3(256), 0, (hipStream_t)stream, g);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
@@ -746,6 +749,7 @@ extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p,
         g.xi[t] = (uint16_t)x_index[t];
         g.pi[t] = (uint16_t)p_index[t];
     }
+    MOAI_CHECK_GRID_ROWS(n_poly * L);
     hipLaunchKernelGGL(ct_pt_dot_kernel, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
@@ -781,6 +785,7 @@ extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, siz
         return MOAI_OK; // a single polynomial keeps its leading rows in place
     }
     const size_t Lout = L - drop;
+    MOAI_CHECK_GRID_ROWS(batch * size * Lout);
     hipLaunchKernelGGL(drop_rows_kernel, row_grid(c, batch * size * Lout), dim3(256), 0, (hipStream_t)stream, in, out,
                        (uint32_t)L, (uint32_t)Lout, (uint32_t)(c->n >> 1));
     MOAI_LAUNCH_CHECK();

@@ -17,7 +17,7 @@
 #include <mutex>
 
 #include "launch.h"
-#include "modarith.cuh"
+#include "modarith.hip.h"
 
 namespace moai {
 
@@ -519,7 +519,11 @@ static int encode_impl(moai_ctx *c, const double *values, const int32_t *mask, i
     {
         return set_error(MOAI_EINVAL, "null argument");
     }
-    rc = ensure_tables(c);
+    rc = enter_device(c);
+    if (!rc)
+    {
+        rc = ensure_tables(c);
+    }
     if (rc)
     {
         return rc;

@@ -22,7 +22,7 @@
 #include "launch.h"
 #include <vector>
 
-#include "keyswitch_kernels.cuh"
+#include "keyswitch_kernels.hip.h"
 
 namespace moai {
 
@@ -379,6 +379,7 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
     e.prime_last = prime_last;
     e.Lout = (uint32_t)Lout;
     e.n2 = (uint32_t)(c->n >> 1);
+    MOAI_CHECK_GRID_ROWS(P * Lout);
     hipLaunchKernelGGL(expand_last_kernel, rgrid(c, P * Lout), dim3(256), 0, s, e);
     MOAI_LAUNCH_CHECK();
     rc = make_rowmap(c, Lout, nullptr, &rm);
@@ -403,6 +404,7 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
     f.addend = addend;
     f.addend_bstride = addend_bstride;
     f.add_mode = add_mode;
+    MOAI_CHECK_GRID_ROWS(P * Lout);
     hipLaunchKernelGGL(moddown_finalize_kernel, rgrid(c, P * Lout), dim3(256), 0, s, f);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
@@ -422,7 +424,7 @@ static int check_level(const moai_ctx *c, size_t L, size_t polys)
     {
         return set_error(MOAI_EINVAL, "batch too large for one launch");
     }
-    return MOAI_OK;
+    return enter_device(c);
 }
 
 struct KsTarget
@@ -440,15 +442,10 @@ static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const u
 // one launch while large batches stay within a few GiB of workspace
 static size_t ks_group_size(const moai_ctx *c, size_t L, size_t batch)
 {
-    static long budget_mb = -1;
-    if (budget_mb < 0)
+    long budget_mb = tuning("MOAI_KS_TMP_MB", 8192);
+    if (budget_mb < 1)
     {
-        const char *e = getenv("MOAI_KS_TMP_MB");
-        budget_mb = e ? atol(e) : 8192;
-        if (budget_mb < 1)
-        {
-            budget_mb = 1;
-        }
+        budget_mb = 1;
     }
     const size_t per_modulus = batch * L * c->n * sizeof(uint64_t);
     size_t g = ((size_t)budget_mb << 20) / (per_modulus ? per_modulus : 1);
@@ -506,7 +503,7 @@ static size_t switch_key_ws_bytes(const moai_ctx *c, size_t L, size_t batch)
            align256(ks_splits(c, L, batch) * batch * 2 * (L + 1) * row_bytes) + align256(batch * 2 * row_bytes);
 }
 
-// which arithmetic the fused kernels use for output modulus `prime` (keyswitch_kernels.cuh): the forward
+// which arithmetic the fused kernels use for output modulus `prime` (keyswitch_kernels.hip.h): the forward
 // transform's mode, with the integer no-guard form only when the lazy digit may also enter the MAC unreduced
 static int ks_mode(const moai_ctx *c, uint32_t prime, size_t L, bool allow_fp)
 {
@@ -608,6 +605,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     const uint32_t n2 = (uint32_t)(n >> 1);
 
     // 1. t = INTT(target)      (evaluator.cpp:2804-2812)
+    MOAI_CHECK_GRID_ROWS(batch * L);
     hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, target, t, (uint32_t)L,
                        (uint32_t)target_stride_rows, (uint32_t)target_off_rows, NO_ZERO, n2);
     MOAI_LAUNCH_CHECK();
@@ -700,6 +698,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         for (size_t Iidx = 0; Iidx <= L; ++Iidx)
         {
             const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+            MOAI_CHECK_GRID_ROWS(batch * L);
             hipLaunchKernelGGL(reduce_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, t, ops, c->pc, prime, n2);
             MOAI_LAUNCH_CHECK();
             for (size_t r = 0; r < L; ++r)
@@ -721,11 +720,13 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             m.prime = prime;
             m.slot = (uint32_t)Iidx;
             m.n2 = n2;
+            MOAI_CHECK_GRID_ROWS(batch);
             hipLaunchKernelGGL(keyswitch_mac_kernel, rgrid(c, batch), dim3(256), 0, s, m);
             MOAI_LAUNCH_CHECK();
         }
     }
     // 3. mod-down by the special prime, accumulated into ct   (evaluator.cpp:2913-3018)
+    MOAI_CHECK_GRID_ROWS(batch * 2);
     hipLaunchKernelGGL(sum_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc, last, (uint32_t)(L + 1), (uint32_t)L, splits,
                        split_stride, c->pc, (uint32_t)(k - 1), n2);
     MOAI_LAUNCH_CHECK();
@@ -772,6 +773,7 @@ extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size
     }
     uint64_t *last = static_cast<uint64_t *>(wsp);
     uint64_t *u = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_last);
+    MOAI_CHECK_GRID_ROWS(P);
     hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1),
                        NO_ZERO, (uint32_t)(c->n >> 1));
     MOAI_LAUNCH_CHECK();
@@ -853,8 +855,10 @@ extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const ui
     }
     uint64_t *last = static_cast<uint64_t *>(wsp);
     uint64_t *u = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_last);
+    MOAI_CHECK_GRID_ROWS(P);
     hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1), NO_ZERO,
                        (uint32_t)(c->n >> 1));
+    MOAI_CHECK_GRID_ROWS(P);
     hipLaunchKernelGGL(scale_rows_kernel, rgrid(c, P), dim3(256), 0, s, last, sc[L - 1], c->primes[L - 1], (uint32_t)(c->n >> 1));
     MOAI_LAUNCH_CHECK();
     return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), nullptr, 0, 0, s, 1, 0, sc);
@@ -1003,6 +1007,7 @@ extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, siz
     g.pc = c->pc;
     g.Lout = (uint32_t)L_out;
     g.n2 = (uint32_t)(c->n >> 1);
+    MOAI_CHECK_GRID_ROWS(P * L_out);
     hipLaunchKernelGGL(modraise_kernel, rgrid(c, P * L_out), dim3(256), 0, s, g);
     MOAI_LAUNCH_CHECK();
     rc = make_rowmap(c, L_out, nullptr, &rm);

@@ -1,4 +1,4 @@
-// keyswitch_kernels.cuh -- the key-switch inner product with the NTT passes fused around it.
+// keyswitch_kernels.hip.h -- the key-switch inner product with the NTT passes fused around it.
 //
 // Reference loop (SEAL/evaluator.cpp:2817-2911), for every output modulus I and digit J:
 //     operand = NTT_{q_I}( t_J mod q_I ) ;  acc_{K,I} += operand (*) key[J][K][I]
@@ -10,7 +10,7 @@
 // shared by the batch through L2) instead of 56 B + key for the unfused sequence
 // reduce -> NTT -> NTT -> MAC.
 #pragma once
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hip.h"
 
 namespace moai {
 
@@ -33,7 +33,7 @@ struct KsP1Args
 };
 
 // work id -> (tile fastest, then group member, digit, ciphertext): neighbours read the same digit tile
-// MODE (modarith.cuh M_*), one per launch: the host groups the output moduli by the arithmetic they allow
+// MODE (modarith.hip.h M_*), one per launch: the host groups the output moduli by the arithmetic they allow
 //   M_GUARD    reference discipline (guard per butterfly, digits normalised with two conditional subtracts)
 //   M_NOGUARD  prime below 2^64/36 and 36 q^2 L < 2^128: no guards, and the unreduced digit (< 33q) goes
 //              straight into the 128-bit MAC

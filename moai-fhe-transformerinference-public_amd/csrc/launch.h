@@ -7,14 +7,18 @@ namespace moai {
 // a tuning knob: the value set through moai_set_tuning, else the environment variable of that name, else dflt
 long tuning(const char *name, long dflt);
 bool noguard_ok(uint64_t q);
-// arithmetic mode (modarith.cuh M_*) of the forward transform under a context prime
+// makes the context's device current for the calling thread (contexts of several devices may live in one process);
+// every operation entry point calls it before it allocates or launches
+int enter_device(const moai_ctx *c);
+// arithmetic mode (modarith.hip.h M_*) of the forward transform under a context prime
 int ntt_mode(const moai_ctx *c, uint32_t prime);
 int make_rowmap(const moai_ctx *c, size_t L, const uint32_t *prime_index, RowMap *out);
 int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse,
                hipStream_t s);
 // returns the context workspace grown to at least `bytes` (grows only outside stream capture)
 int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out);
-int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out);
+// headroom: allocate max(1.25 x bytes, 1.5 x the current size) when the arena has to grow
+int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out, bool headroom);
 // device pointer to the Galois permutation table of `elt` (built on first use)
 int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out);
 

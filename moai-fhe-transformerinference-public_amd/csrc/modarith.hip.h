@@ -1,4 +1,4 @@
-// modarith.cuh -- 64-bit modular arithmetic for CDNA4 (no native 64-bit multiplier: everything
+// modarith.hip.h -- 64-bit modular arithmetic for CDNA4 (no native 64-bit multiplier: everything
 // lowers to v_mad_u64_u32 / v_mul_hi_u32 chains).  Any algorithm is admissible as long as the final
 // canonical residues equal the reference's (SEAL/util/uintarithsmallmod.h:167-326).
 #pragma once
@@ -62,12 +62,6 @@ __device__ __forceinline__ uint64_t barrett64(uint64_t x, uint64_t q, uint64_t c
 // dwthandler.h:110-163)
 __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
-#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
-    // diagnostic build only (tools/ablate.sh): data movement without the arithmetic
-    x += y + w;
-    y ^= wq + q + q2;
-    return;
-#endif
     uint64_t u = csub(x, q2);
     uint64_t v = mul_shoup_lazy(y, w, wq, q);
     x = u + v;
@@ -79,11 +73,6 @@ __device__ __forceinline__ void ct_bfly(uint64_t &x, uint64_t &y, uint64_t w, ui
 // finishes the transform reduces with one Barrett step.  Same residues as ct_bfly.
 __device__ __forceinline__ void ct_bfly_noguard(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
-#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
-    x += y + w;
-    y ^= wq + q + q2;
-    return;
-#endif
     uint64_t v = mul_shoup_lazy(y, w, wq, q);
     uint64_t u = x;
     x = u + v;
@@ -194,11 +183,6 @@ __device__ __forceinline__ void ct_bfly_fp1(uint64_t &xb, uint64_t &yb, double w
 template <bool GUARDED>
 __device__ __forceinline__ void ct_bfly_guard2(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
-#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
-    x += y + w;
-    y ^= wq + q + q2;
-    return;
-#endif
     uint64_t u = GUARDED ? csub(x, q2 << 1) : x;
     uint64_t v = mul_shoup_lazy(y, w, wq, q);
     x = u + v;
@@ -235,11 +219,6 @@ __device__ __forceinline__ void ct_bfly_t(uint64_t &x, uint64_t &y, uint64_t w, 
 // Gentleman-Sande butterfly, lazy: x, y in [0, 2q) -> [0, 2q)   (dwthandler.h:226-250)
 __device__ __forceinline__ void gs_bfly(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
-#if defined(MOAI_ABLATE) && MOAI_ABLATE == 1
-    x += y + w;
-    y ^= wq + q + q2;
-    return;
-#endif
     uint64_t u = x;
     uint64_t v = y;
     x = csub(u + v, q2);

@@ -1,7 +1,7 @@
 // ntt.hip -- launchers of the negacyclic NTT kernels (C ABI: moai_ntt_forward / moai_ntt_inverse).
 #include <cstdlib>
 
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hip.h"
 #include "launch.h"
 
 namespace moai {
@@ -62,7 +62,7 @@ static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
         }
         switch (mode)
         {
-        case M_GUARD: launch_fwd_mode<LOGN, M_GUARD2>(c, a, s); break; // same residues, half the guards (modarith.cuh)
+        case M_GUARD: launch_fwd_mode<LOGN, M_GUARD2>(c, a, s); break; // same residues, half the guards (modarith.hip.h)
         case M_NOGUARD: launch_fwd_mode<LOGN, M_NOGUARD>(c, a, s); break;
         case M_FPN: launch_fwd_mode<LOGN, M_FPN>(c, a, s); break;
         default: launch_fwd_mode<LOGN, M_FPR>(c, a, s); break;
@@ -82,13 +82,13 @@ static void launch_inv(const NttArgs &base, hipStream_t s)
 
 } // namespace moai
 namespace moai {
-// 36 q < 2^64: forward butterflies may skip the per-stage guard (modarith.cuh ct_bfly_noguard)
+// 36 q < 2^64: forward butterflies may skip the per-stage guard (modarith.hip.h ct_bfly_noguard)
 bool noguard_ok(uint64_t q)
 {
     return q < (~0ull) / 36;
 }
 
-// the arithmetic mode of the forward transform under context prime `prime` (modarith.cuh M_*):
+// the arithmetic mode of the forward transform under context prime `prime` (modarith.hip.h M_*):
 // FP64 below 2^51 (MOAI_NTT_FP=0 keeps everything on the integer units), else integer with or without guards
 int ntt_mode(const moai_ctx *c, uint32_t prime)
 {
@@ -237,7 +237,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
         if (coop)
         {
             void *st = nullptr;
-            int rc = reserve_for_stream(c, (void *)((uintptr_t)s ^ 1u), coop_state_bytes(c, n_poly * L), &st);
+            int rc = reserve_for_stream(c, (void *)((uintptr_t)s ^ 1u), coop_state_bytes(c, n_poly * L), &st, false);
             if (rc)
             {
                 return rc;
@@ -346,6 +346,10 @@ static int ntt_entry(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const
     }
     RowMap rows;
     int rc = make_rowmap(c, L, prime_index, &rows);
+    if (!rc)
+    {
+        rc = enter_device(c);
+    }
     if (rc)
     {
         return rc;

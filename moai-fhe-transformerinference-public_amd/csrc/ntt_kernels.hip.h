@@ -1,4 +1,4 @@
-// ntt_kernels.cuh -- negacyclic NTT / INTT for gfx950.
+// ntt_kernels.hip.h -- negacyclic NTT / INTT for gfx950.
 //
 // What it computes is the reference's ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey
 // (SEAL/util/ntt.cpp:394-475, butterflies SEAL/util/dwthandler.h:94-356): forward = Cooley-Tukey,
@@ -18,7 +18,7 @@
 // Lazy ranges: forward keeps values in [0,4q) between stages, inverse in [0,2q), like the
 // reference; the pass that finishes a transform writes canonical residues.
 #pragma once
-#include "modarith.cuh"
+#include "modarith.hip.h"
 
 namespace moai {
 

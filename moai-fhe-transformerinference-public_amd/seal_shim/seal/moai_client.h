@@ -3,15 +3,148 @@
 //  but needed so that MOAI's programs link and run.  Their NTTs are
 // executed on the device through moai_ntt_forward / moai_ntt_inverse.
 #pragma once
+#include <cerrno>
+#include <cstdio>
 #include <cstring>
+#include <stdexcept>
+
+#include <sys/random.h>
+#include <sys/types.h>
 
 namespace seal
 {
     namespace util
     {
-        inline std::mt19937_64 &thread_rng()
+        // Randomness of the client side: ChaCha20 (RFC 8439 block function, 20 rounds) in counter mode, keyed per thread
+        // with 256 bits + a 64-bit nonce drawn from the operating system (getrandom(2), /dev/urandom as a fallback).
+        // The reference expands a 512-bit OS seed with Blake2xb / Shake256 (SEAL/randomgen.cpp:18-62, 142-169); the
+        // construction differs, the property does not: every secret (ternary key, uniform a, noise, u / e0 / e1) comes
+        // from a cryptographic stream whose state cannot be recovered from the public outputs.  Satisfies the C++
+        // UniformRandomBitGenerator requirements, so the standard distributions below take it.
+        class ChaCha20Rng
         {
-            static thread_local std::mt19937_64 g{ std::random_device{}() ^ 0x9E3779B97F4A7C15ull };
+        public:
+            using result_type = std::uint64_t;
+            static constexpr result_type min()
+            {
+                return 0;
+            }
+            static constexpr result_type max()
+            {
+                return ~static_cast<result_type>(0);
+            }
+            ChaCha20Rng()
+            {
+                unsigned char seed[40];
+                os_random(seed, sizeof(seed));
+                init(seed);
+            }
+            // a fixed stream (known-answer test of the block function): 32-byte key + 8-byte nonce
+            explicit ChaCha20Rng(const unsigned char (&seed)[40])
+            {
+                init(seed);
+            }
+            result_type operator()()
+            {
+                if (pos_ == 8)
+                {
+                    refill();
+                }
+                return buf_[pos_++];
+            }
+            static void os_random(unsigned char *out, std::size_t len)
+            {
+                std::size_t got = 0;
+                while (got < len)
+                {
+                    ssize_t r = ::getrandom(out + got, len - got, 0);
+                    if (r > 0)
+                    {
+                        got += static_cast<std::size_t>(r);
+                    }
+                    else if (r < 0 && errno == EINTR)
+                    {
+                        continue;
+                    }
+                    else
+                    {
+                        break;
+                    }
+                }
+                if (got < len)
+                {
+                    std::FILE *f = std::fopen("/dev/urandom", "rb");
+                    if (f)
+                    {
+                        got += std::fread(out + got, 1, len - got, f);
+                        std::fclose(f);
+                    }
+                }
+                if (got < len)
+                {
+                    throw std::runtime_error("no operating-system randomness available");
+                }
+            }
+
+        private:
+            static std::uint32_t rotl(std::uint32_t v, int c)
+            {
+                return (v << c) | (v >> (32 - c));
+            }
+            static void quarter(std::uint32_t *x, int a, int b, int c, int d)
+            {
+                x[a] += x[b];
+                x[d] = rotl(x[d] ^ x[a], 16);
+                x[c] += x[d];
+                x[b] = rotl(x[b] ^ x[c], 12);
+                x[a] += x[b];
+                x[d] = rotl(x[d] ^ x[a], 8);
+                x[c] += x[d];
+                x[b] = rotl(x[b] ^ x[c], 7);
+            }
+            void init(const unsigned char *seed)
+            {
+                static const std::uint32_t sigma[4] = { 0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u }; // "expand 32-byte k"
+                std::memcpy(state_, sigma, 16);
+                std::memcpy(state_ + 4, seed, 32);      // key
+                state_[12] = state_[13] = 0;            // 64-bit block counter
+                std::memcpy(state_ + 14, seed + 32, 8); // nonce
+                pos_ = 8;
+            }
+            void refill()
+            {
+                std::uint32_t x[16];
+                std::memcpy(x, state_, sizeof(x));
+                for (int i = 0; i < 10; i++)
+                {
+                    quarter(x, 0, 4, 8, 12);
+                    quarter(x, 1, 5, 9, 13);
+                    quarter(x, 2, 6, 10, 14);
+                    quarter(x, 3, 7, 11, 15);
+                    quarter(x, 0, 5, 10, 15);
+                    quarter(x, 1, 6, 11, 12);
+                    quarter(x, 2, 7, 8, 13);
+                    quarter(x, 3, 4, 9, 14);
+                }
+                for (int i = 0; i < 16; i++)
+                {
+                    x[i] += state_[i];
+                }
+                std::memcpy(buf_, x, sizeof(buf_));
+                if (++state_[12] == 0)
+                {
+                    ++state_[13];
+                }
+                pos_ = 0;
+            }
+            std::uint32_t state_[16];
+            std::uint64_t buf_[8];
+            int pos_ = 8;
+        };
+
+        inline ChaCha20Rng &thread_rng()
+        {
+            static thread_local ChaCha20Rng g;
             return g;
         }
 

@@ -32,6 +32,17 @@ def max_over_ranks(seconds, dist, device=None):
     return float(t.item())
 
 
+def sum_over_ranks(units, dist, device=None):
+    """Units all ranks processed together."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(units)
+    import torch
+
+    u = torch.tensor([float(units)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(u.item())
+
+
 def whole_job_rate(units_this_rank, seconds_this_rank, dist, device=None):
     """(sum over ranks of units) / (max over ranks of seconds): the aggregate the bench reports."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -458,7 +458,7 @@ def test_config2_shape_properties(moai):
 
 @pytest.mark.parametrize("logn", [12, 13, 15, 16])
 def test_forward_ntt_guard_every_second_stage(moai, logn):
-    """59..61-bit primes take the integer butterflies with one guard per two stages (modarith.cuh M_GUARD2, values up
+    """59..61-bit primes take the integer butterflies with one guard per two stages (modarith.hip.h M_GUARD2, values up
     to 8q < 2^64): canonical extremes and lazy inputs up to 4q - 1, the documented input range, against the oracle."""
     n = 1 << logn
     primes = O.coeff_modulus_create(n, [61, 61, 60, 59])
@@ -615,7 +615,7 @@ def test_key_switch_replays_from_a_hip_graph(moai, ks_arith):
 
 
 def test_fp64_modes_at_their_size_limits(moai):
-    """Primes at the edges of the FP64 arithmetic modes (modarith.cuh): the largest ones below 2^51 (M_FPR), around
+    """Primes at the edges of the FP64 arithmetic modes (modarith.hip.h): the largest ones below 2^51 (M_FPR), around
     2^52 / 33 where M_FPN ends, and a 52-bit one that must stay on the integer units; worst-case magnitudes
     (all residues q - 1, key and digits alike) and random data, forward NTT and key switch against the oracle."""
     logn = 12

@@ -24,8 +24,16 @@ def _worker(rank, world, port, q):
     seconds = 2.0 if rank == 1 else 1.0
     t = m.shard.max_over_ranks(seconds, dist)
     rate = m.shard.whole_job_rate(float(count), seconds, dist)
+    # what `bench.py --gpus 2 --split` transforms on this rank (strong scaling: one 256-ciphertext batch shared), and
+    # what it transforms without --split (weak scaling: a whole batch per rank); the job's rows are summed over ranks
+    import bench
+
+    split = bench.batch_of_rank(256, rank, world, True, m.shard)
+    weak = bench.batch_of_rank(256, rank, world, False, m.shard)
+    job_split = m.shard.sum_over_ranks(float(split[0]), dist)
+    job_weak = m.shard.sum_over_ranks(float(weak[0]), dist)
     m.shard.barrier(dist)
-    q.put((rank, start, count, t, rate))
+    q.put((rank, start, count, t, rate, split, weak, job_split, job_weak))
     dist.destroy_process_group()
 
 
@@ -42,7 +50,11 @@ def test_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, c0, t0, rate0), (r1, s1, c1, t1, rate1) = res
+    (r0, s0, c0, t0, rate0, split0, weak0, js0, jw0), (r1, s1, c1, t1, rate1, split1, weak1, js1, jw1) = res
+    # --split: rank 0 transforms ciphertexts [0, 128), rank 1 [128, 256) of the ONE batch; without it 256 each
+    assert split0 == (128, 0) and split1 == (128, 128)
+    assert weak0 == (256, 0) and weak1 == (256, 256)
+    assert js0 == js1 == 256.0 and jw0 == jw1 == 512.0
     assert (s0, c0) == (0, 129) and (s1, c1) == (129, 128)  # disjoint, covers all 257 ciphertexts
     assert t0 == t1 == 2.0  # max over ranks
     assert rate0 == rate1 == pytest.approx(257 / 2.0)  # all units / slowest rank

@@ -63,3 +63,32 @@ def test_cpp_binary_passes_on_gpu(binary):
         pytest.skip("built from MOAI's own headers, which only the build container holds")
     r = subprocess.run([os.path.join(CPP, binary)], cwd=CPP, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ALL PASS" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_client_randomness_is_a_chacha20_stream(tmp_path):
+    """seal::KeyGenerator / Encryptor draw from ChaCha20 keyed by the OS (moai_client.h).  Known answer: the first block
+    of the all-zero key and nonce (draft-agl-tls-chacha20poly1305-04 section 7, test vector 1), and two generators
+    seeded from the OS do not repeat each other."""
+    src = tmp_path / "rng.cpp"
+    src.write_text(r'''
+#include "seal/seal.h"
+#include <cstdio>
+int main() {
+    unsigned char seed[40] = {0};
+    seal::util::ChaCha20Rng g(seed);
+    for (int i = 0; i < 8; i++) { unsigned long long v = g(); for (int b = 0; b < 8; b++) std::printf("%02x", (unsigned)((v >> (8 * b)) & 0xff)); }
+    std::printf("\n");
+    seal::util::ChaCha20Rng a, b;
+    std::printf("%d\n", a() == b() ? 1 : 0);
+    return 0;
+}
+''')
+    exe = tmp_path / "rng"
+    r = _gxx([str(src), "-o", str(exe), "-L" + PKG, "-lmoai_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.split()
+    assert lines[0] == ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                        "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    assert lines[1] == "0"

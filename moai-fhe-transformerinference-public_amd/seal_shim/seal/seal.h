@@ -542,6 +542,18 @@ namespace seal
     // =================================================================================================
     // EncryptionParameters  (SEAL/encryptionparams.h)
     // =================================================================================================
+    namespace util
+    {
+        // SEAL/util/iterator.h iter(...) as MOAI uses it on the modulus vector (include/source/bootstrapping/
+        // Bootstrapper.cpp:2344, :2481, :3235: `iter(...coeff_modulus())[i].value()`): indexed read access.  The raw
+        // residue iterators over a Ciphertext (only Bootstrapper::modraise_inplace, :2973-2975) are not offered: the
+        // data lives on the device, and that routine is the C ABI's moai_modraise.
+        inline const std::vector<Modulus> &iter(const std::vector<Modulus> &v) noexcept
+        {
+            return v;
+        }
+    } // namespace util
+
     class EncryptionParameters
     {
     public:
@@ -596,6 +608,11 @@ namespace seal
         {
             return coeff_modulus_;
         }
+        // BFV / BGV only (SEAL/encryptionparams.h:330-333): zero for CKKS, as in the reference
+        const Modulus &plain_modulus() const noexcept
+        {
+            return plain_modulus_;
+        }
         std::size_t secret_key_hamming_weight() const noexcept
         {
             return secret_key_hamming_weight_;
@@ -609,6 +626,7 @@ namespace seal
         scheme_type scheme_;
         std::size_t poly_modulus_degree_ = 0;
         std::vector<Modulus> coeff_modulus_;
+        Modulus plain_modulus_;
         std::size_t secret_key_hamming_weight_ = 0;
         std::size_t sparse_slots_ = 0;
     };

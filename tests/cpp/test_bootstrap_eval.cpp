@@ -31,7 +31,10 @@ static int g_fail = 0;
         }                                                                  \
     } while (0)
 
-#include "ref_bootstrap_calls.h"
+#include "ref_bootstrapper.h" // the reference's own transform routines, sliced from the checkout at build time
+
+using namespace seal;
+using namespace std;
 
 using moai_fused::ChebyshevHeap;
 using moai_fused::ModularReducer3;
@@ -139,6 +142,13 @@ int main(int argc, char **argv)
     Evaluator evaluator(context, encoder);
     const double scale = pow(2.0, 42);
     const int Nh = (int)encoder.slot_count();
+    refslice::Bootstrapper ref(logn, logn, scale, context, encoder, evaluator, gal_keys);
+    auto ref_bsgs = [&](Evaluator &, GaloisKeys &, int, Ciphertext &out, Ciphertext &in, int totlen, int basicstep, int coeff_logn,
+                        const vector<vector<complex<double>>> &coeff) { ref.bsgs_linear_transform(out, in, totlen, basicstep, coeff_logn, coeff); };
+    auto ref_rotated_bsgs = [&](Evaluator &, GaloisKeys &, int, Ciphertext &out, Ciphertext &in, int totlen, int basicstep, int coeff_logn,
+                                const vector<vector<complex<double>>> &coeff) {
+        ref.rotated_bsgs_linear_transform(out, in, totlen, basicstep, coeff_logn, coeff);
+    };
     mt19937_64 rng(11);
     uniform_real_distribution<double> ud(-1.0, 1.0);
 

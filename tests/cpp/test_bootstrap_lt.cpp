@@ -24,7 +24,10 @@ static int g_fail = 0;
         }                                                                  \
     } while (0)
 
-#include "ref_bootstrap_calls.h"
+#include "ref_bootstrapper.h" // the reference's own transform routines, sliced from the checkout at build time
+
+using namespace seal;
+using namespace std;
 
 int main()
 {
@@ -46,6 +49,13 @@ int main()
     Evaluator evaluator(context, encoder);
     const double scale = pow(2.0, 46);
     const int Nh = (int)encoder.slot_count();
+    refslice::Bootstrapper ref(11, 11, scale, context, encoder, evaluator, gal_keys);
+    auto ref_bsgs = [&](Evaluator &, GaloisKeys &, int, Ciphertext &out, Ciphertext &in, int totlen, int basicstep, int coeff_logn,
+                        const vector<vector<complex<double>>> &coeff) { ref.bsgs_linear_transform(out, in, totlen, basicstep, coeff_logn, coeff); };
+    auto ref_rotated_bsgs = [&](Evaluator &, GaloisKeys &, int, Ciphertext &out, Ciphertext &in, int totlen, int basicstep, int coeff_logn,
+                                const vector<vector<complex<double>>> &coeff) {
+        ref.rotated_bsgs_linear_transform(out, in, totlen, basicstep, coeff_logn, coeff);
+    };
     mt19937_64 rng(5);
     uniform_real_distribution<double> ud(-1.0, 1.0);
 

@@ -1,0 +1,296 @@
+// A bootstrap that bootstraps: the drop-in Bootstrapper (seal_shim/bootstrapping/Bootstrapper.h) driven exactly the way
+// MOAI's drivers drive the reference's (include/test/test_full_scheme.hpp:345-448: constructor, prepare_mod_polynomial,
+// the key list, create_galois_keys, slot_vec, generate_LT_coefficient_3; :642-660: mod-switch to the lowest level, then
+// bootstrap_3 from an OpenMP loop), with the REAL constants -- the re-derived transform diagonals and the minimax
+// cosine -- and the check the reference's own drivers only print: decrypt(bootstrap_3(ct)) against the message.
+//
+//   part 1  N = 2^11 (logn = 10, full slots), same primes sizes / K / degree / double-angle count / Hamming weight as MOAI
+//   part 2  N = 2^16, MOAI's exact parameters (36-prime chain, logn = 15): `--full`
+// Both check: chain index after = total - 14 (boot_level, test_full_scheme.hpp:364), output scale = final_scale,
+// max |decoded - message| below the bound stated next to each assertion; calls gathered from concurrent threads give the
+// bits of single calls.
+#include <execinfo.h>
+#include <omp.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "Bootstrapper.h"
+#include "ref_bootstrapper.h" // the reference's own bootstrap_full_3 and its transforms, sliced from the checkout at build time
+
+static int g_checks = 0, g_fail = 0;
+#define CHECK(cond)                                                \
+    do                                                             \
+    {                                                              \
+        g_checks++;                                                \
+        if (!(cond))                                               \
+        {                                                          \
+            g_fail++;                                              \
+            printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+        }                                                          \
+    } while (0)
+
+static double now_s()
+{
+    return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// returns the largest error over the design range
+static void run(int logN, int remaining_level, int n_threads, int per_thread, bool timing)
+{
+    // include/test/test_full_scheme.hpp:345-378
+    long boundary_K = 25;
+    long deg = 59;
+    long scale_factor = 2;
+    long inverse_deg = 1;
+    long loge = 10;
+    long logn = logN - 1;
+    int logp = 46, logq = 51, log_special_prime = 58;
+    int secret_key_hamming_weight = 192;
+    int boot_level = 14;
+    int total_level = remaining_level + boot_level;
+    vector<int> coeff_bit_vec;
+    coeff_bit_vec.push_back(logq);
+    for (int i = 0; i < remaining_level; i++) coeff_bit_vec.push_back(logp);
+    for (int i = 0; i < boot_level; i++) coeff_bit_vec.push_back(logq);
+    coeff_bit_vec.push_back(log_special_prime);
+
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t poly_modulus_degree = (size_t)(1 << logN);
+    parms.set_poly_modulus_degree(poly_modulus_degree);
+    parms.set_coeff_modulus(CoeffModulus::Create(poly_modulus_degree, coeff_bit_vec));
+    parms.set_secret_key_hamming_weight(secret_key_hamming_weight);
+    double scale = pow(2.0, logp);
+    SEALContext context(parms, true, sec_level_type::none);
+
+    KeyGenerator keygen(context);
+    SecretKey secret_key = keygen.secret_key();
+    PublicKey public_key;
+    keygen.create_public_key(public_key);
+    RelinKeys relin_keys;
+    keygen.create_relin_keys(relin_keys);
+    GaloisKeys gal_keys_boot;
+    Encryptor encryptor(context, public_key);
+    Decryptor decryptor(context, secret_key);
+    CKKSEncoder encoder(context);
+    Evaluator evaluator(context, encoder);
+    size_t slot_count = encoder.slot_count();
+
+    double t0 = now_s();
+    Bootstrapper bootstrapper(loge, logn, logN - 1, total_level, scale, boundary_K, deg, scale_factor, inverse_deg, context, keygen, encoder,
+                              encryptor, decryptor, evaluator, relin_keys, gal_keys_boot);
+    bootstrapper.prepare_mod_polynomial();
+    double t_poly = now_s() - t0;
+    vector<int> gal_steps_vector;
+    gal_steps_vector.push_back(0);
+    for (int i = 0; i < logN - 1; i++) gal_steps_vector.push_back((1 << i));
+    bootstrapper.addLeftRotKeys_Linear_to_vector_3(gal_steps_vector);
+    t0 = now_s();
+    keygen.create_galois_keys(gal_steps_vector, gal_keys_boot);
+    context.sync();
+    double t_keys = now_s() - t0;
+    bootstrapper.slot_vec.push_back(logn);
+    t0 = now_s();
+    bootstrapper.generate_LT_coefficient_3();
+    double t_lt = now_s() - t0;
+    printf("N = 2^%d: %zu primes, %zu rotation keys in %.1f s, polynomials %.2f s (minimax error %.3e), diagonals %.2f s\n", logN,
+           coeff_bit_vec.size(), gal_steps_vector.size(), t_keys, t_poly, bootstrapper.mod_reducer->sin_cos_minimax_error, t_lt);
+    CHECK(fabs(bootstrapper.mod_reducer->sin_cos_minimax_error - 1.9362149866592e-10) < 1e-18);
+
+    mt19937_64 rng(logN);
+    uniform_real_distribution<double> ud(-1.0, 1.0);
+    auto fresh = [&](double magnitude, vector<complex<double>> &msg, Ciphertext &ct) {
+        msg.resize(slot_count);
+        for (auto &z : msg) z = { ud(rng) * magnitude, ud(rng) * magnitude };
+        Plaintext p;
+        encoder.encode(msg, scale, p);
+        encryptor.encrypt(p, ct);
+        // test_full_scheme.hpp:642-646
+        while (context.get_context_data(ct.parms_id())->chain_index() != 0) evaluator.mod_switch_to_next_inplace(ct);
+    };
+    auto max_error = [&](const Ciphertext &ct, const vector<complex<double>> &msg) {
+        Plaintext p;
+        decryptor.decrypt(ct, p);
+        vector<complex<double>> dec;
+        encoder.decode(p, dec);
+        double e = 0;
+        for (size_t i = 0; i < slot_count; i++) e = max(e, abs(dec[i] - msg[i]));
+        return e;
+    };
+    const size_t top = context.first_context_data()->chain_index();
+
+    // --- one call; message inside the range the reduction is fitted for: |m| scale / q0 <= 2^-loge, i.e. |m| <= 2^-5 at
+    // MOAI's scale 2^46 under its 51-bit q0
+    {
+        vector<complex<double>> msg;
+        Ciphertext ct, out;
+        fresh(0.02, msg, ct);
+        const double before = max_error(ct, msg);
+        t0 = now_s();
+        bootstrapper.bootstrap_3(out, ct);
+        context.sync();
+        const double first = now_s() - t0;
+        const size_t after = context.get_context_data(out.parms_id())->chain_index();
+        const double err = max_error(out, msg);
+        printf("  |m| <= 0.02: chain index 0 -> %zu of %zu, scale 2^%.1f, max |error| before %.2e, after bootstrap_3 %.2e (first call %.2f s)\n",
+               after, top, log2(out.scale()), before, err, first);
+        CHECK(after == top - 14);
+        CHECK(out.scale() == scale);
+        CHECK(out.is_ntt_form() && out.size() == 2);
+        // error budget: the cosine fit (1.9e-10) through two double-angle steps and the q0 / (2 pi scale) = 5.1 factor is
+        // ~1e-8, the linear inverse sine 1.5e-9 * 32 = 5e-8, encryption + key-switch + rescale noise of 35 levels at
+        // scale 2^46 a few 1e-7 for N = 2^16; the reference claims about 20 bits after the point (2025-991.pdf section 5)
+        CHECK(err < 2e-5);
+        // a second call reuses every cached diagonal set and gives the same quality
+        Ciphertext ct2, out2;
+        vector<complex<double>> msg2;
+        fresh(0.02, msg2, ct2);
+        t0 = now_s();
+        bootstrapper.bootstrap_3(out2, ct2);
+        context.sync();
+        printf("  second call %.3f s\n", now_s() - t0);
+        CHECK(max_error(out2, msg2) < 2e-5);
+        // the refreshed ciphertext computes: square it, as the layers after a bootstrap do
+        Ciphertext sq;
+        evaluator.square(out, sq);
+        evaluator.relinearize_inplace(sq, relin_keys);
+        evaluator.rescale_to_next_inplace(sq);
+        vector<complex<double>> msq(slot_count);
+        for (size_t i = 0; i < slot_count; i++) msq[i] = msg[i] * msg[i];
+        CHECK(max_error(sq, msq) < 2e-5);
+    }
+    // --- MOAI's activations are not confined to that range: magnitudes up to 1 work with the sine's cubic error
+    // (2 pi m / 32)^2 / 6 relative, 0.64 % at |m| = 1
+    {
+        vector<complex<double>> msg;
+        Ciphertext ct, out;
+        fresh(0.7, msg, ct);
+        bootstrapper.bootstrap_3(out, ct);
+        const double err = max_error(out, msg);
+        printf("  |m| <= 0.7 (outside the fitted range): max |error| %.2e\n", err);
+        CHECK(err < 0.7 * 1.4142 * 0.0065 * 1.2);
+    }
+    // --- MOAI's calling pattern: concurrent single-ciphertext calls (gathered into packs) against calls made alone
+    {
+        const int total = n_threads * per_thread;
+        vector<vector<complex<double>>> msgs(total);
+        vector<Ciphertext> in(total), alone(total), gathered(total);
+        for (int i = 0; i < total; i++) fresh(0.02, msgs[i], in[i]);
+        for (int i = 0; i < min(total, 3); i++)
+        {
+            Ciphertext c = in[i];
+            bootstrapper.bootstrap_full_3(alone[i], c); // no gathering
+        }
+        // the reference's own source text for bootstrap_full_3 (its transforms, coefficient-to-slot and slot-to-coefficient
+        // steps; tests/cpp/ref_bootstrapper.h), one ciphertext through the shim's evaluator with the same constants: same bits
+        {
+            refslice::Bootstrapper ref(logn, logN - 1, scale, context, encoder, evaluator, gal_keys_boot);
+            moai_fused::BootDiagonals3 d;
+            d.fftcoeff1 = bootstrapper.fftcoeff1[0];
+            d.fftcoeff2 = bootstrapper.fftcoeff2[0];
+            d.fftcoeff3 = bootstrapper.fftcoeff3[0];
+            d.invfftcoeff1 = bootstrapper.invfftcoeff1[0];
+            d.invfftcoeff2 = bootstrapper.invfftcoeff2[0];
+            d.invfftcoeff3 = bootstrapper.invfftcoeff3[0];
+            ref.set_diagonals(d);
+            ref.mod_reducer = bootstrapper.mod_reducer;
+            Ciphertext c = in[0], want;
+            t0 = now_s();
+            ref.bootstrap_3(want, c);
+            context.sync();
+            printf("  the reference's call sequence on one ciphertext: %.2f s\n", now_s() - t0);
+            CHECK(want.parms_id() == alone[0].parms_id() && want.scale() == alone[0].scale());
+            CHECK(want.download() == alone[0].download());
+        }
+        const auto before = bootstrapper.gather_statistics();
+        t0 = now_s();
+#pragma omp parallel for num_threads(n_threads)
+        for (int t = 0; t < n_threads; t++)
+        {
+            for (int j = 0; j < per_thread; j++)
+            {
+                Ciphertext c = in[t * per_thread + j];
+                bootstrapper.bootstrap_3(gathered[t * per_thread + j], c);
+            }
+        }
+        context.sync();
+        const double dt = now_s() - t0;
+        const auto after = bootstrapper.gather_statistics();
+        const size_t runs = after.first - before.first, members = after.second - before.second;
+        printf("  %d threads x %d calls: %zu packed runs for %zu ciphertexts, %.1f ms per bootstrap\n", n_threads, per_thread, runs, members,
+               dt / total * 1e3);
+        CHECK(members == (size_t)total);
+        CHECK(n_threads == 1 || runs < members);
+        for (int i = 0; i < min(total, 3); i++)
+        {
+            CHECK(gathered[i].parms_id() == alone[i].parms_id() && gathered[i].scale() == alone[i].scale());
+            CHECK(gathered[i].download() == alone[i].download());
+        }
+        double worst = 0;
+        for (int i = 0; i < total; i++) worst = max(worst, max_error(gathered[i], msgs[i]));
+        CHECK(worst < 2e-5);
+        if (timing)
+        {
+            printf("  worst error over the %d gathered bootstraps %.2e\n", total, worst);
+        }
+    }
+    // --- refusals (Bootstrapper.cpp:2939-2945) and what is not provided
+    {
+        auto throws = [&](auto &&f) {
+            try
+            {
+                f();
+            }
+            catch (const std::exception &)
+            {
+                return true;
+            }
+            return false;
+        };
+        Ciphertext topct, out;
+        Plaintext p;
+        encoder.encode(0.5, scale, p);
+        encryptor.encrypt(p, topct);
+        CHECK(throws([&] { bootstrapper.bootstrap_3(out, topct); })); // not at the lowest level
+        CHECK(throws([&] { bootstrapper.bootstrap(out, topct); }));
+    }
+}
+
+static void on_fault(int sig)
+{
+    void *frames[64];
+    int n = backtrace(frames, 64);
+    const char msg[] = "fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(128 + sig);
+}
+
+int main(int argc, char **argv)
+{
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    signal(SIGSEGV, on_fault);
+    signal(SIGABRT, on_fault);
+    const bool full = argc > 1 && !strcmp(argv[1], "--full");
+    const int threads = argc > 2 ? atoi(argv[2]) : 4;
+    const int per_thread = argc > 3 ? atoi(argv[3]) : 2;
+    if (!full)
+    {
+        run(11, 2, 4, 2, false);
+    }
+    else
+    {
+        run(16, 20, threads, per_thread, true);
+    }
+    printf("%d checks, %d failed\n", g_checks, g_fail);
+    if (!g_fail)
+    {
+        printf("ALL PASS\n");
+    }
+    return g_fail ? 1 : 0;
+}

@@ -47,6 +47,8 @@ def test_cpp_test_binaries_are_built():
     assert os.path.exists(os.path.join(CPP, "test_moai_headers"))
     assert os.path.exists(os.path.join(CPP, "test_bootstrap_lt"))
     assert os.path.exists(os.path.join(CPP, "test_bootstrap_eval"))
+    assert os.path.exists(os.path.join(CPP, "test_bootstrap_setup"))
+    assert os.path.exists(os.path.join(CPP, "test_bootstrap_real"))
 
 
 def test_bootstrap_polynomial_heap_host_checks():
@@ -56,8 +58,31 @@ def test_bootstrap_polynomial_heap_host_checks():
     assert r.returncode == 0 and "ALL PASS" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
+def test_bootstrap_setup_constants_host_checks():
+    """The bootstrapping constants are re-derived without NTL (seal_shim/bootstrapping/moai_remez.h, moai_fft_diagonals.h).
+    Host-only: equioscillation of the minimax cosine / inverse sine, F P = U and G F = identity / 2K for the diagonals
+    (tests/cpp/test_bootstrap_setup.cpp), and the cosine's coefficients against an independent 400-bit computation of
+    the same polynomial (tests/golden/remez_cos_K25_deg59_loge10_r2.json, written by tools/remez_mpmath.py)."""
+    import json
+
+    exe = os.path.join(CPP, "test_bootstrap_setup")
+    r = subprocess.run([exe], cwd=CPP, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL PASS" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "remez_cos_K25_deg59_loge10_r2.json")))
+    r = subprocess.run([exe, "--print-cos", str(gold["boundary_K"]), str(gold["log_width"]), str(gold["deg"]), str(gold["scale_factor"])],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vals = [float(x) for x in r.stdout.split()]
+    want = [float(x) for x in gold["chebcoeff"]]
+    assert abs(vals[0] - float(gold["minimax_error"])) < 1e-22
+    assert len(vals) == len(want) + 1
+    # as doubles: equal to the last place or one off it
+    for got, w in zip(vals[1:], want):
+        assert abs(got - w) <= 2.3e-16 * abs(w), (got, w)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers", "test_bootstrap_lt", "test_bootstrap_eval"])
+@pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers", "test_bootstrap_lt", "test_bootstrap_eval", "test_bootstrap_real"])
 def test_cpp_binary_passes_on_gpu(binary):
     if binary == "test_moai_headers" and not os.path.exists(os.path.join(CPP, binary)) and not os.path.isdir(REF):
         pytest.skip("built from MOAI's own headers, which only the build container holds")

@@ -130,7 +130,10 @@ int main()
     gettimeofday(&t1, NULL);
     printf("\nsingle_att_block (MOAI's header, unchanged): %.2f s\n", t1.tv_sec - t0.tv_sec + (t1.tv_usec - t0.tv_usec) / 1e6);
     CHECK(out.size() == (size_t)col_W);
-    CHECK(context.get_context_data(out[0].parms_id())->chain_index() == 2); // "softmax*V (3 -> 2)", 2025-991.pdf table 3
+    // QK^T at index 13, exp and its mask 13 -> 4, the 16-step inverse 20 -> 3, the normalisation -> 2 = V's level, the product
+    // with V -> 1 ("softmax 13 -> 3, softmax*V 3 -> 2" in 2025-991.pdf table 3, which counts levels from 1)
+    printf("output at chain index %zu\n", context.get_context_data(out[0].parms_id())->chain_index());
+    CHECK(context.get_context_data(out[0].parms_id())->chain_index() == 1);
 
     // ---- the same attention in the clear, with MOAI's approximations
     const double q0 = (double)context.first_context_data()->parms().coeff_modulus()[0].value();
@@ -205,8 +208,8 @@ int main()
     printf("scores in [%.2f, %.2f] (shifted by %.1f), largest sum of exponentials %.3f\n", smin, smax, minus_index, summax);
     printf("max |decrypted - attention with MOAI's approximations| = %.3e ; against the exact softmax attention %.3e\n", worst, worst_vs_true);
     CHECK(smax < minus_index && summax < 1.9); // inside the domain the reference's approximations are built for
-    CHECK(worst < 5e-3);
-    CHECK(worst_vs_true < 0.1);
+    CHECK(worst < 2e-3);
+    CHECK(worst_vs_true < 5e-3);
     const auto gs = bootstrapper.gather_statistics();
     printf("bootstrap_3 calls: %zu in %zu runs\n", gs.second, gs.first);
     CHECK(gs.second == 1);

@@ -258,6 +258,15 @@ int moai_ckks_tables(moai_ctx *ctx, uint32_t *index_map, double *inv_root_powers
  *   MOAI_KS_FP_MIN_ROWS  batch * L from which the key switch uses the FP64 arithmetic modes (default 16) */
 int moai_set_tuning(const char *name, long value);
 
+/* ---- operation census ----------------------------------------------------------------------------------------------
+ * moai_op_trace(1) clears and starts, moai_op_trace(0) stops counting what the entry points above were asked to do:
+ * per (entry point, level L) the sum of the call's own batch argument (polynomials for the element-wise and NTT calls,
+ * ciphertexts for the scheme-level ones, terms x polynomials for the fused sums).  bench.py uses it to price the same
+ * operations on the CPU oracle.  moai_op_trace_dump writes "name L count" lines (NUL-terminated, truncated to cap)
+ * and returns the size the whole text needs.  Off by default; costs one relaxed atomic load per call. */
+int moai_op_trace(int enable);
+size_t moai_op_trace_dump(char *buf, size_t cap);
+
 /* ---- measurement support -----------------------------------------------------------------------------------
  * Average duration in milliseconds of the NTT kernels of the last moai_ntt_* call recorded with
  * HIP events on the caller's stream is not provided here; callers time with their own events

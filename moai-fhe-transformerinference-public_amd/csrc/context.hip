@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <thread>
 
@@ -32,6 +33,20 @@ const char *last_error()
 
 static std::mutex g_tuning_mu;
 static std::map<std::string, long> g_tuning;
+
+static std::atomic<int> g_trace_on{ 0 };
+static std::mutex g_trace_mu;
+static std::map<std::pair<std::string, size_t>, unsigned long long> g_trace;
+
+void trace_op(const char *name, size_t L, size_t units)
+{
+    if (!g_trace_on.load(std::memory_order_relaxed))
+    {
+        return;
+    }
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    g_trace[std::make_pair(std::string(name), L)] += units;
+}
 
 int enter_device(const moai_ctx *c)
 {
@@ -235,6 +250,34 @@ extern "C" int moai_set_tuning(const char *name, long value)
     std::lock_guard<std::mutex> g(g_tuning_mu);
     g_tuning[name] = value;
     return MOAI_OK;
+}
+
+extern "C" int moai_op_trace(int enable)
+{
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    if (enable)
+    {
+        g_trace.clear();
+    }
+    g_trace_on.store(enable ? 1 : 0);
+    return MOAI_OK;
+}
+
+extern "C" size_t moai_op_trace_dump(char *buf, size_t cap)
+{
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    std::string out;
+    for (const auto &kv : g_trace)
+    {
+        out += kv.first.first + " " + std::to_string(kv.first.second) + " " + std::to_string(kv.second) + "\n";
+    }
+    if (buf && cap)
+    {
+        const size_t nbytes = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), nbytes);
+        buf[nbytes] = 0;
+    }
+    return out.size() + 1;
 }
 
 extern "C" int moai_version(void)

@@ -536,23 +536,27 @@ using namespace moai;
 extern "C" int moai_add(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
                         void *stream)
 {
+    trace_op("add", L, n_poly);
     return ew_launch<EW_ADD>(c, a, b, out, n_poly, n_poly, L, stream);
 }
 
 extern "C" int moai_sub(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
                         void *stream)
 {
+    trace_op("sub", L, n_poly);
     return ew_launch<EW_SUB>(c, a, b, out, n_poly, n_poly, L, stream);
 }
 
 extern "C" int moai_negate(moai_ctx *c, const uint64_t *a, uint64_t *out, size_t n_poly, size_t L, void *stream)
 {
+    trace_op("negate", L, n_poly);
     return ew_launch<EW_NEG>(c, a, nullptr, out, n_poly, n_poly, L, stream);
 }
 
 extern "C" int moai_dyadic_mul(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly,
                                size_t n_poly_b, size_t L, void *stream)
 {
+    trace_op("dyadic_mul", L, n_poly);
     if (n_poly_b != n_poly && n_poly_b != 1)
     {
         return set_error(MOAI_EINVAL, "n_poly_b must be n_poly or 1");
@@ -606,12 +610,14 @@ static int scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, 
 extern "C" int moai_mul_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
                                     size_t n_poly, size_t L, void *stream)
 {
+    trace_op("mul_scalar_rows", L, n_poly);
     return scalar_rows(c, a, scalars, out, n_poly, L, stream, true);
 }
 
 extern "C" int moai_add_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
                                     size_t n_poly, size_t L, void *stream)
 {
+    trace_op("add_scalar_rows", L, n_poly);
     return scalar_rows(c, a, scalars, out, n_poly, L, stream, false);
 }
 
@@ -659,17 +665,20 @@ static int ct_mul(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *o
 extern "C" int moai_ct_multiply(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t L,
                                 size_t batch, void *stream)
 {
+    trace_op("ct_multiply", L, batch);
     return ct_mul(c, x, y, out, L, batch, stream, false);
 }
 
 extern "C" int moai_ct_square(moai_ctx *c, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream)
 {
+    trace_op("ct_square", L, batch);
     return ct_mul(c, x, x, out, L, batch, stream, true);
 }
 
 extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t count, size_t L,
                            void *stream)
 {
+    trace_op("ct_dot", L, count);
     int rc = check_rows(c, count * 2, L);
     if (rc)
     {
@@ -707,6 +716,7 @@ extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, ui
 extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
                               const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream)
 {
+    trace_op("ct_pt_dot", L, n_poly * terms);
     int rc = check_rows(c, n_poly, L);
     if (rc)
     {
@@ -758,6 +768,7 @@ extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p,
 extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,
                              size_t batch, void *stream)
 {
+    trace_op("mod_drop", L, batch * size);
     int rc = check_rows(c, batch * size, L);
     if (rc)
     {
@@ -795,6 +806,7 @@ extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, siz
 extern "C" int moai_galois_permute(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t n_poly, size_t L,
                                    uint32_t galois_elt, void *stream)
 {
+    trace_op("galois_permute", L, n_poly);
     int rc = check_rows(c, n_poly, L);
     if (rc)
     {
@@ -854,6 +866,7 @@ extern "C" uint32_t moai_galois_elt_from_step(const moai_ctx *c, int step)
 extern "C" int moai_ct_pt_matmul(moai_ctx *c, const uint64_t *x, const uint64_t *w, uint64_t *out, size_t rows,
                                  size_t cols, size_t size, size_t L, void *stream)
 {
+    trace_op("ct_pt_matmul", L, rows * cols * size);
     int rc = check_rows(c, (rows > cols ? rows : cols) * size, L);
     if (rc)
     {

@@ -579,6 +579,7 @@ extern "C" int moai_ckks_encode(moai_ctx *c, const double *values, int is_comple
                                 size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index, double scale,
                                 double *max_coeff, void *stream)
 {
+    trace_op("ckks_encode", L, n_batch);
     return encode_impl(c, values, nullptr, is_complex, values_size, n_batch, dst, L, prime_index, scale, max_coeff, stream);
 }
 
@@ -586,6 +587,7 @@ extern "C" int moai_ckks_encode_masked(moai_ctx *c, const double *constants, con
                                        size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index,
                                        double scale, double *max_coeff, void *stream)
 {
+    trace_op("ckks_encode_masked", L, n_batch);
     if (!mask && mask_size > 0)
     {
         return set_error(MOAI_EINVAL, "mask cannot be null");

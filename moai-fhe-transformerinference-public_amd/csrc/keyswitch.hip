@@ -741,6 +741,7 @@ using namespace moai;
 extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
                             void *stream)
 {
+    trace_op("rescale", L, batch * size);
     const size_t P = batch * size;
     int rc = check_level(c, L, P);
     if (rc)
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(uint64_t *rows, Tw s, u
 extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
                                        size_t L, size_t batch, void *stream)
 {
+    trace_op("mul_scalar_rescale", L, batch * size);
     const size_t P = batch * size;
     int rc = check_level(c, L, P);
     if (rc)
@@ -867,6 +869,7 @@ extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const ui
 extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,
                                size_t batch, void *stream)
 {
+    trace_op("switch_key", L, batch);
     int rc = check_level(c, L, batch * 2);
     if (rc)
     {
@@ -893,6 +896,7 @@ extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target
 extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t *relin_key, uint64_t *out, size_t L,
                                 size_t batch, void *stream)
 {
+    trace_op("relinearize", L, batch);
     int rc = check_level(c, L, batch * 3);
     if (rc)
     {
@@ -922,6 +926,7 @@ extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t
 extern "C" int moai_apply_galois_to(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L, uint32_t galois_elt,
                                     const uint64_t *galois_key, size_t batch, void *stream)
 {
+    trace_op("apply_galois_to", L, batch);
     int rc = check_level(c, L, batch * 2);
     if (rc)
     {
@@ -965,6 +970,7 @@ extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t g
 
 extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream)
 {
+    trace_op("modraise", L_out, batch);
     const size_t P = batch * 2;
     int rc = check_level(c, L_out, P);
     if (rc)

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
         {
             lds_a[phys8_a((b << 8) | ((uint32_t)j << 5) | r)] = x[j];
         }
-        lds_barrier();
+        lds_wave_sync(); // block b's 32 threads are half a wave: both exchanges stay inside one wave
 #pragma unroll
         for (int j = 0; j < 8; ++j)
         {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
         {
             lds_b[phys8_b((b << 8) | (hi3 << 5) | ((uint32_t)j << 2) | lo2)] = x[j];
         }
-        lds_barrier();
+        lds_wave_sync(); // block b's 32 threads are half a wave: both exchanges stay inside one wave
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {

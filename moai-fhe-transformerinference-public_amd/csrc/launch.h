@@ -6,6 +6,9 @@ namespace moai {
 
 // a tuning knob: the value set through moai_set_tuning, else the environment variable of that name, else dflt
 long tuning(const char *name, long dflt);
+// operation census for the end-to-end bench (moai_op_trace): counts `units` (polynomials, ciphertexts or products, as the
+// entry point's own batch argument counts them) per (entry point, level); a relaxed atomic load when it is off
+void trace_op(const char *name, size_t L, size_t units);
 bool noguard_ok(uint64_t q);
 // makes the context's device current for the calling thread (contexts of several devices may live in one process);
 // every operation entry point calls it before it allocates or launches

@@ -360,11 +360,13 @@ static int ntt_entry(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const
 extern "C" int moai_ntt_forward(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
                                 void *stream)
 {
+    trace_op("ntt_forward", L, n_poly);
     return ntt_entry(c, data, n_poly, L, prime_index, stream, false);
 }
 
 extern "C" int moai_ntt_inverse(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
                                 void *stream)
 {
+    trace_op("ntt_inverse", L, n_poly);
     return ntt_entry(c, data, n_poly, L, prime_index, stream, true);
 }

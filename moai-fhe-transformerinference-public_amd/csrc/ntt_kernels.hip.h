@@ -40,6 +40,14 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Exchange between lanes of ONE wave through LDS: a wave's LDS instructions execute in issue order, so data written by
+// one lane is there for another lane of the same wave once the wave's LDS counter has drained; no s_barrier, the
+// other waves of the workgroup run on.  (The asm also keeps the compiler from moving LDS accesses across it.)
+__device__ __forceinline__ void lds_wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // ---- LDS tile layouts ------------------------------------------------------------------------------
 // contiguous pass: element e of the 4096-tile lives in 16-byte chunk (e>>1); chunks are XOR-swizzled
 // within each 128-byte row so that "one row per lane" (ds_*_b128) and "one column per lane"
@@ -322,7 +330,8 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     {
         lds[phys_contig((b << 8) | ((uint32_t)j << 4) | tl)] = x[j];
     }
-    __syncthreads();
+    // a 256-block belongs to 16 consecutive threads, i.e. to one wave: every exchange of this pass is wave-local
+    lds_wave_sync();
     const uint32_t myrow = tid; // (b << 4) | th
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -346,7 +355,7 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             }
         }
     }
-    __syncthreads(); // every thread has read its row before anyone overwrites the tile
+    // a thread overwrites the row it alone has read
 #pragma unroll
     for (int c = 0; c < 8; ++c)
     {
@@ -374,11 +383,13 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
         }
         lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
     }
-    __syncthreads();
+    lds_wave_sync();
+    // every wave stores the 64 rows (8 KiB, contiguous in memory) its own lanes finished: 1 KiB per wave instruction
+    const uint32_t wbase = (tid >> 6) << 9, lane = tid & 63u;
 #pragma unroll
     for (int it = 0; it < 8; ++it)
     {
-        uint32_t ch = (uint32_t)it * 256u + tid;
+        uint32_t ch = wbase + (uint32_t)it * 64u + lane;
         uint32_t rr = ch >> 3;
         store(ch, lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))]);
     }
@@ -437,14 +448,16 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
         tb[i] = twbt[((uint32_t)i << 8) + tid];
     }
     const ulonglong2 *__restrict__ in2 = reinterpret_cast<const ulonglong2 *>(base);
+    // every wave stages the 64 rows its own lanes transform (8 KiB, contiguous): the exchanges of this pass are wave-local
+    const uint32_t wbase = (tid >> 6) << 9, lane = tid & 63u;
 #pragma unroll
     for (int it = 0; it < 8; ++it)
     {
-        uint32_t ch = (uint32_t)it * 256u + tid;
+        uint32_t ch = wbase + (uint32_t)it * 64u + lane;
         uint32_t rr = ch >> 3;
         lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))] = in2[ch];
     }
-    __syncthreads();
+    lds_wave_sync();
     const uint32_t myrow = tid;
     uint64_t x[16];
 #pragma unroll
@@ -477,7 +490,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
         v.y = x[2 * c + 1];
         lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))] = v;
     }
-    __syncthreads();
+    lds_wave_sync();
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {

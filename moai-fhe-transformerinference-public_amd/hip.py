@@ -65,6 +65,8 @@ SYMBOLS = {
     "moai_total_coeff_modulus_bit_count": (C.c_int, [vp, sz, C.POINTER(C.c_uint32)]),
     "moai_ckks_tables": (C.c_int, [vp, vp, vp]),
     "moai_set_tuning": (C.c_int, [C.c_char_p, C.c_long]),
+    "moai_op_trace": (C.c_int, [C.c_int]),
+    "moai_op_trace_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "moai_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
     "moai_event_create": (C.c_int, [C.POINTER(vp)]),
     "moai_event_destroy": (C.c_int, [vp]),
@@ -345,6 +347,23 @@ class Context:
 
 def set_tuning(name, value):
     _check(lib().moai_set_tuning(name.encode(), int(value)))
+
+
+def op_trace(enable):
+    """start (True: clears the counters) or stop the census of operations the entry points are asked to perform"""
+    _check(lib().moai_op_trace(1 if enable else 0))
+
+
+def op_trace_counts():
+    """{(entry point, level): units} counted since op_trace(True)"""
+    need = lib().moai_op_trace_dump(None, 0)
+    buf = C.create_string_buffer(need + 16)
+    lib().moai_op_trace_dump(buf, need + 16)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, level, count = line.split()
+        out[(name, int(level))] = int(count)
+    return out
 
 
 def device_info(device=0):

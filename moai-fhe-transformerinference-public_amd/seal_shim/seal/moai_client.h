@@ -152,9 +152,12 @@ namespace seal
         inline void sample_uniform(const std::vector<std::uint64_t> &primes, std::size_t n, std::vector<std::uint64_t> &out)
         {
             out.resize(primes.size() * n);
-            auto &g = thread_rng();
+            // rows are independent and every thread owns its generator: a switching key at MOAI's size draws 35 x 36 x
+            // 65536 residues, which one host thread takes about a second for
+#pragma omp parallel for schedule(dynamic)
             for (std::size_t r = 0; r < primes.size(); r++)
             {
+                auto &g = thread_rng();
                 std::uniform_int_distribution<std::uint64_t> d(0, primes[r] - 1);
                 for (std::size_t i = 0; i < n; i++)
                 {
@@ -169,6 +172,7 @@ namespace seal
         {
             const std::size_t n = poly.size();
             out.resize(primes.size() * n);
+#pragma omp parallel for schedule(static)
             for (std::size_t r = 0; r < primes.size(); r++)
             {
                 const std::uint64_t q = primes[r];

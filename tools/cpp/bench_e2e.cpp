@@ -1,0 +1,287 @@
+// bench_e2e.cpp -- the bounded end-to-end slice bench.py runs as a child process (BASELINE metric, first half:
+// "ms per encrypted input, 128 tokens, 12 layers"): at MOAI's exact parameters (N = 2^16, the 36-prime chain, logn = 15,
+// K = 25, degree 59, Hamming weight 192; include/test/test_full_scheme.hpp:345-448)
+//   1. bootstrap_3 on `pack` ciphertexts, (a) as one packed run and (b) the way MOAI's driver calls it -- one ciphertext per
+//      call from an OpenMP loop (test_full_scheme.hpp:654-660), which the drop-in Bootstrapper gathers into packed runs;
+//   2. one attention head through MOAI's OWN single_att_block.hpp / softmax.hpp / matrix-product headers, unchanged
+//      (included from the reference checkout at build time; the binary travels prebuilt), on 768 input ciphertexts
+//      carrying 256 packed inputs, with the decrypted result checked against the attention computed in the clear.
+// Weights and inputs are synthetic (the reference's dense weights are not in its checkout, .MISSING_LARGE_BLOBS).
+// While each part runs, the library's operation census (moai_op_trace) records what the evaluator was asked to do per
+// level; bench.py prices those counts on the CPU oracle of the same host.  Last line: `E2E_JSON {...}`.
+#include "seal/seal.h"
+
+#include <omp.h>
+#include <sys/time.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <vector>
+
+#include "Batch_encode_encrypt.hpp"
+#include "Ct_pt_matrix_mul.hpp"
+#include "Ct_ct_matrix_mul.hpp"
+#include "softmax.hpp"
+#include "single_att_block.hpp"
+
+static double now_s()
+{
+    return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static string census_json()
+{
+    size_t need = moai_op_trace_dump(nullptr, 0);
+    vector<char> buf(need + 16);
+    moai_op_trace_dump(buf.data(), buf.size());
+    stringstream in(buf.data()), out;
+    string name;
+    size_t level;
+    unsigned long long count;
+    out << "[";
+    bool first = true;
+    while (in >> name >> level >> count)
+    {
+        out << (first ? "" : ",") << "[\"" << name << "\"," << level << "," << count << "]";
+        first = false;
+    }
+    out << "]";
+    return out.str();
+}
+
+int main(int argc, char **argv)
+{
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const int pack = argc > 1 ? atoi(argv[1]) : 48;
+    const int threads = argc > 2 ? atoi(argv[2]) : omp_get_max_threads();
+    const bool with_head = !(argc > 3 && !strcmp(argv[3], "--no-head"));
+    omp_set_num_threads(threads);
+    const double t_start = now_s();
+
+    // ---- include/test/test_full_scheme.hpp:345-448 ----------------------------------------------------------------
+    long boundary_K = 25, deg = 59, scale_factor = 2, inverse_deg = 1;
+    long logN = 16, loge = 10, logn = 15;
+    int logp = 46, logq = 51, log_special_prime = 58;
+    int remaining_level = 20, boot_level = 14, total_level = remaining_level + boot_level;
+    vector<int> coeff_bit_vec;
+    coeff_bit_vec.push_back(logq);
+    for (int i = 0; i < remaining_level; i++) coeff_bit_vec.push_back(logp);
+    for (int i = 0; i < boot_level; i++) coeff_bit_vec.push_back(logq);
+    coeff_bit_vec.push_back(log_special_prime);
+    EncryptionParameters parms(scheme_type::ckks);
+    size_t poly_modulus_degree = (size_t)(1 << logN);
+    parms.set_poly_modulus_degree(poly_modulus_degree);
+    parms.set_coeff_modulus(CoeffModulus::Create(poly_modulus_degree, coeff_bit_vec));
+    parms.set_secret_key_hamming_weight(192);
+    double scale = pow(2.0, logp);
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    SecretKey secret_key = keygen.secret_key();
+    PublicKey public_key;
+    keygen.create_public_key(public_key);
+    RelinKeys relin_keys;
+    keygen.create_relin_keys(relin_keys);
+    GaloisKeys gal_keys;
+    if (with_head)
+    {
+        keygen.create_galois_keys(gal_keys);
+    }
+    GaloisKeys gal_keys_boot;
+    Encryptor encryptor(context, public_key);
+    Decryptor decryptor(context, secret_key);
+    CKKSEncoder encoder(context);
+    Evaluator evaluator(context, encoder);
+    size_t slot_count = encoder.slot_count();
+    Bootstrapper bootstrapper(loge, logn, logN - 1, total_level, scale, boundary_K, deg, scale_factor, inverse_deg, context, keygen, encoder,
+                              encryptor, decryptor, evaluator, relin_keys, gal_keys_boot);
+    bootstrapper.prepare_mod_polynomial();
+    vector<int> gal_steps_vector;
+    gal_steps_vector.push_back(0);
+    for (int i = 0; i < logN - 1; i++) gal_steps_vector.push_back((1 << i));
+    bootstrapper.addLeftRotKeys_Linear_to_vector_3(gal_steps_vector);
+    keygen.create_galois_keys(gal_steps_vector, gal_keys_boot);
+    bootstrapper.slot_vec.push_back(logn);
+    bootstrapper.generate_LT_coefficient_3();
+    context.sync();
+    const double setup_s = now_s() - t_start;
+    printf("setup (context, %zu + %d rotation keys, relinearization key, bootstrapping constants): %.1f s\n", gal_steps_vector.size(),
+           with_head ? 31 : 0, setup_s);
+
+    mt19937_64 rng(2);
+    uniform_real_distribution<double> ud(-1.0, 1.0);
+
+    // ---- 1. bootstrapping -------------------------------------------------------------------------------------------
+    vector<vector<complex<double>>> msgs(pack, vector<complex<double>>(slot_count));
+    vector<Ciphertext> low(pack);
+    for (int i = 0; i < pack; i++)
+    {
+        for (auto &z : msgs[i]) z = { ud(rng) * 0.02, ud(rng) * 0.02 };
+        Plaintext p;
+        encoder.encode(msgs[i], scale, p);
+        encryptor.encrypt(p, low[i]);
+        evaluator.mod_switch_to_inplace(low[i], context.last_parms_id()); // test_full_scheme.hpp:642-646
+    }
+    {
+        // untimed first run at the full pack size: encodes and caches the diagonals of every (level, scale) and grows the
+        // library's workspace arena to what a pack of this size needs
+        Ciphertext warm = moai_fused::pack(low, context), out;
+        bootstrapper.bootstrap_full_3(out, warm);
+        context.sync();
+    }
+    Ciphertext packed = moai_fused::pack(low, context), packed_out;
+    moai_op_trace(1);
+    double t0 = now_s();
+    bootstrapper.bootstrap_full_3(packed_out, packed);
+    context.sync();
+    const double boot_packed_ms = (now_s() - t0) / pack * 1e3;
+    moai_op_trace(0);
+    const string ops_boot = census_json();
+    vector<Ciphertext> outs(pack);
+    t0 = now_s();
+#pragma omp parallel for
+    for (int i = 0; i < pack; i++)
+    {
+        Ciphertext c = low[i];
+        bootstrapper.bootstrap_3(outs[i], c);
+    }
+    context.sync();
+    const double boot_calls_ms = (now_s() - t0) / pack * 1e3;
+    double boot_err = 0;
+    for (int i = 0; i < pack; i += max(1, pack / 4))
+    {
+        Plaintext p;
+        decryptor.decrypt(outs[i], p);
+        vector<complex<double>> dec;
+        encoder.decode(p, dec);
+        for (size_t s = 0; s < slot_count; s++) boot_err = max(boot_err, abs(dec[s] - msgs[i][s]));
+    }
+    const size_t boot_index = context.get_context_data(outs[0].parms_id())->chain_index();
+    printf("bootstrap_3: %.2f ms per ciphertext in one pack of %d; %.2f ms through %d single-ciphertext calls from %d threads; "
+           "chain index 0 -> %zu, max |error| %.2e\n",
+           boot_packed_ms, pack, boot_calls_ms, pack, threads, boot_index, boot_err);
+    low.clear();
+    outs.clear();
+    packed = Ciphertext();
+    packed_out = Ciphertext();
+
+    // ---- 2. one attention head, MOAI's headers unchanged ------------------------------------------------------------
+    double head_s = -1, head_err = -1, head_err_true = -1;
+    string ops_head = "[]";
+    if (with_head)
+    {
+        const int num_X = 256, num_row = 128, num_col = 768, col_W = 64, input_num = 5, layer_id = 0, iter = 16;
+        const double minus_index = 7.5;
+        vector<vector<vector<double>>> X(num_X, vector<vector<double>>(num_row, vector<double>(num_col, 0.0)));
+        vector<int> input_len(num_X, 0);
+        input_len[0] = input_num; // test_full_scheme.hpp:455-457: one real input of 5 tokens in the packed batch
+        for (int k = 0; k < input_num; k++)
+            for (int i = 0; i < num_col; i++) X[0][k][i] = ud(rng);
+        vector<int> b_vec = bias_vec(input_len, num_X, num_row);
+        vector<vector<double>> WQ(num_col, vector<double>(col_W)), WK(num_col, vector<double>(col_W)), WV(num_col, vector<double>(col_W));
+        vector<double> bQ(col_W), bK(col_W), bV(col_W);
+        for (int r = 0; r < num_col; r++)
+            for (int c = 0; c < col_W; c++)
+            {
+                WQ[r][c] = 0.004 * ud(rng);
+                WK[r][c] = 0.004 * ud(rng);
+                WV[r][c] = 0.02 * ud(rng);
+            }
+        for (int c = 0; c < col_W; c++)
+        {
+            bQ[c] = 0.28;
+            bK[c] = 0.28;
+            bV[c] = 0.3 * ud(rng);
+        }
+        t0 = now_s();
+        vector<Ciphertext> enc_X = batch_input(X, num_X, num_row, num_col, scale, context, public_key);
+#pragma omp parallel for
+        for (int i = 0; i < num_col; i++)
+            while (context.get_context_data(enc_X[i].parms_id())->chain_index() > 15) evaluator.mod_switch_to_next_inplace(enc_X[i]);
+        context.sync();
+        printf("768 input ciphertexts encrypted and switched to chain index 15: %.1f s\n", now_s() - t0);
+        moai_op_trace(1);
+        t0 = now_s();
+        vector<Ciphertext> out = single_att_block(enc_X, WQ, WK, WV, bQ, bK, bV, b_vec, input_num, context, relin_keys, gal_keys, bootstrapper,
+                                                  num_X, secret_key, iter, layer_id);
+        context.sync();
+        head_s = now_s() - t0;
+        moai_op_trace(0);
+        ops_head = census_json();
+        // the same head in the clear with MOAI's approximations (tests/cpp/test_moai_attention.cpp explains the model)
+        auto approx_exp = [](double x) { return pow(1 + x * 0.0078125, 128); };
+        auto goldschmidt = [&](double x) {
+            double y = 1 - x, res = 1 + y;
+            for (int i = 0; i < iter; i++)
+            {
+                y = y * y;
+                res *= 1 + y;
+            }
+            return res;
+        };
+        vector<vector<double>> Q(input_num, vector<double>(col_W)), Km(input_num, vector<double>(col_W)), V(input_num, vector<double>(col_W));
+        for (int k = 0; k < input_num; k++)
+            for (int c = 0; c < col_W; c++)
+            {
+                double q = bQ[c], kk = bK[c], v = bV[c];
+                for (int i = 0; i < num_col; i++)
+                {
+                    q += X[0][k][i] * WQ[i][c];
+                    kk += X[0][k][i] * WK[i][c];
+                    v += X[0][k][i] * WV[i][c];
+                }
+                Q[k][c] = q;
+                Km[k][c] = kk;
+                V[k][c] = v;
+            }
+        head_err = head_err_true = 0;
+        double smax = -1e9, summax = 0;
+        for (int c = 0; c < col_W; c += 7)
+        {
+            Plaintext p;
+            vector<double> dec;
+            decryptor.decrypt(out[c], p);
+            encoder.decode(p, dec);
+            for (int k = 0; k < input_num; k++)
+            {
+                vector<double> e(input_num), et(input_num);
+                double sum = 0, sumt = 0;
+                for (int k2 = 0; k2 < input_num; k2++)
+                {
+                    double s = 0;
+                    for (int cc = 0; cc < col_W; cc++) s += Q[k][cc] * Km[k2][cc];
+                    smax = max(smax, s);
+                    e[k2] = approx_exp(s - minus_index);
+                    et[k2] = exp(s - minus_index);
+                    sum += e[k2];
+                    sumt += et[k2];
+                }
+                summax = max(summax, sum);
+                const double inv = goldschmidt(sum + 0.00001);
+                double want = 0, truth = 0;
+                for (int k2 = 0; k2 < input_num; k2++)
+                {
+                    want += e[k2] * inv * V[k2][c];
+                    truth += et[k2] / sumt * V[k2][c];
+                }
+                head_err = max(head_err, fabs(dec[(size_t)num_X * k] - want));
+                head_err_true = max(head_err_true, fabs(dec[(size_t)num_X * k] - truth));
+            }
+        }
+        printf("\nsingle_att_block (MOAI's header, unchanged; 768 x 64 weights, 128 token rows, 256 packed inputs): %.2f s; output at chain index "
+               "%zu; largest score %.2f, largest sum of exponentials %.3f; max |decrypted - clear attention| %.2e (exact softmax: %.2e)\n",
+               head_s, context.get_context_data(out[0].parms_id())->chain_index(), smax, summax, head_err, head_err_true);
+    }
+    printf("E2E_JSON {\"pack\": %d, \"threads\": %d, \"setup_s\": %.2f, \"bootstrap_ms_packed\": %.3f, \"bootstrap_ms_moai_calls\": %.3f, "
+           "\"bootstrap_chain_index_after\": %zu, \"bootstrap_max_error\": %.3e, \"head_s\": %.3f, \"head_max_error\": %.3e, "
+           "\"head_max_error_vs_exact_softmax\": %.3e, \"ops_bootstrap_pack\": %s, \"ops_head\": %s}\n",
+           pack, threads, setup_s, boot_packed_ms, boot_calls_ms, boot_index, boot_err, head_s, head_err, head_err_true, ops_boot.c_str(),
+           ops_head.c_str());
+    return 0;
+}

@@ -3,8 +3,8 @@
 // packed inputs of 128 tokens, 12 heads, 3072 intermediate ciphertexts, four bootstrapping rounds of 768.
 // Every stage runs through the batched replacements of this repository (each of which is tested bit-identical to
 // MOAI's own loop or call sequence) or through MOAI's unchanged headers (layernorm.hpp, gelu_others.hpp on packs):
-//   attention head x 12   Q, K, V products + bias (single_att_block.hpp:30-98), Q K^T (:119-125), softmax_boot
-//                         (softmax.hpp:307-580, as its call sequence: the header needs NTL), softmax . V (:186-197)
+//   attention head x 12   Q, K, V products + bias (single_att_block.hpp:30-98), Q K^T (:119-125), MOAI's own softmax_boot
+//                         (softmax.hpp:307-580, header unchanged), softmax . V (:186-197)
 //   self-output product   ct_pt_matrix_mul_wo_pre_w_mask 768 x 768 + bias (test_full_scheme.hpp:601-617)
 //   bootstrap round 1     768 x bootstrap_3 (:654-660), residual add (:663-667)
 //   LayerNorm 1           layernorm() (:668)
@@ -15,9 +15,9 @@
 //   bootstrap round 3     (:990-995), residual add (:998-1002)
 //   LayerNorm 2           layernorm2() (:1004)
 //   bootstrap round 4     (:1080-1087)
-// Weights are synthetic N(0, 0.02) (the reference's dense weights are not in the checkout); the bootstrap uses
-// stand-in constants (seal/moai_bootstrap_eval.h), so values lose their meaning after the first bootstrap: this
-// binary measures time, the per-stage correctness checks live in the tests and the per-stage drivers.
+// Weights are synthetic N(0, 0.02) (the reference's dense weights are not in the checkout); the bootstrap is the drop-in
+// Bootstrapper with its real constants.  This binary measures time; the per-stage correctness checks live in the tests
+// (tests/cpp/test_moai_headers.cpp, test_moai_attention.cpp, test_bootstrap_real.cpp).
 // usage: bench_encoder_layer [heads = 12] [bootstrap packs per round = all] [gelu packs = 48] [bootstrap pack size = 48]
 //   smaller numbers make a quick plumbing run: the remaining work is skipped and its results are copies.
 #include "seal/seal.h"
@@ -38,154 +38,13 @@
 #include "Ct_pt_matrix_mul.hpp"
 #include "gelu_others.hpp"
 #include "layernorm.hpp"
+#include "softmax.hpp" // MOAI's own softmax_boot, unchanged; brings in the drop-in Bootstrapper (seal_shim/bootstrapping)
 
-#include "seal/moai_bootstrap_eval.h"
 #include "seal/moai_fused.h"
 
 static double now_s()
 {
     return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// softmax.hpp:9-27
-static Ciphertext exp_ct(const Ciphertext &x, CKKSEncoder &encoder, Evaluator &evaluator, const RelinKeys &relin_keys)
-{
-    Plaintext inverse_128;
-    encoder.encode(0.0078125, x.parms_id(), x.scale(), inverse_128);
-    Ciphertext output;
-    evaluator.multiply_plain(x, inverse_128, output);
-    evaluator.rescale_to_next_inplace(output);
-    Plaintext one;
-    encoder.encode(1.0, output.parms_id(), output.scale(), one);
-    evaluator.add_plain_inplace(output, one);
-    for (int i = 0; i < log2(128); ++i)
-    {
-        evaluator.square_inplace(output);
-        evaluator.relinearize_inplace(output, relin_keys);
-        evaluator.rescale_to_next_inplace(output);
-    }
-    return output;
-}
-
-// softmax.hpp:29-52
-static Ciphertext inverse_ct(const Ciphertext &x, CKKSEncoder &encoder, Evaluator &evaluator, const RelinKeys &relin_keys, int iter)
-{
-    Plaintext one;
-    encoder.encode(1.0, x.parms_id(), x.scale(), one);
-    Ciphertext y;
-    evaluator.sub_plain(x, one, y);
-    evaluator.negate_inplace(y);
-    Ciphertext tmp;
-    evaluator.add_plain(y, one, tmp);
-    Ciphertext res = tmp;
-    for (int i = 0; i < iter; ++i)
-    {
-        evaluator.square_inplace(y);
-        evaluator.relinearize_inplace(y, relin_keys);
-        evaluator.rescale_to_next_inplace(y);
-        encoder.encode(1.0, y.parms_id(), y.scale(), one);
-        evaluator.add_plain(y, one, tmp);
-        evaluator.mod_switch_to_inplace(res, tmp.parms_id());
-        evaluator.multiply_inplace(res, tmp);
-        evaluator.relinearize_inplace(res, relin_keys);
-        evaluator.rescale_to_next_inplace(res);
-    }
-    return res;
-}
-
-static vector<double> mask_vector(int i, int num, int input_num, int num_batch, const vector<int> &bias_vec, double value)
-{
-    const int slot_count = (int)bias_vec.size();
-    vector<double> v;
-    if (i == 0)
-    {
-        v.assign(slot_count, 0);
-        for (int s = 0; s < slot_count; ++s)
-            if (bias_vec[s] == 1) v[s] = value;
-    }
-    else if (i > input_num && i <= (num - input_num))
-    {
-    }
-    else if (i <= input_num)
-    {
-        v.assign(slot_count, 0);
-        int index = num_batch * (input_num - i);
-        for (int s = 0; s < slot_count; ++s)
-            if (bias_vec[s] == 1 && s < index) v[s] = value;
-    }
-    else if (i > num - input_num)
-    {
-        v.assign(slot_count, 0);
-        int index = (num - i) * num_batch;
-        for (int s = 0; s < slot_count; ++s)
-            if (bias_vec[s] == 1 && s >= index) v[s] = value;
-    }
-    return v;
-}
-
-// softmax_boot (softmax.hpp:307-580) on packed ciphertexts; tools/cpp/bench_softmax.cpp checks this sequence bit for
-// bit against the per-ciphertext one
-static vector<Ciphertext> softmax_boot_packed(const vector<Ciphertext> &enc_X, const vector<int> &bias_vec, int input_num, const SEALContext &context,
-                                              CKKSEncoder &encoder, Evaluator &evaluator, const RelinKeys &relin_keys, int iter,
-                                              moai_fused::PackedBootstrapper3 &boot, double minus_index)
-{
-    const int num = (int)enc_X.size(), num_batch = (int)encoder.slot_count() / 128;
-    const double scale = enc_X[0].scale();
-    vector<Ciphertext> enc_x_minus(num);
-    for (int i = 0; i < num; ++i)
-    {
-        enc_x_minus[i] = enc_X[i];
-        vector<double> m = mask_vector(i, num, input_num, num_batch, bias_vec, minus_index);
-        if (!m.empty())
-        {
-            Plaintext one;
-            encoder.encode(m, enc_x_minus[i].scale(), one);
-            evaluator.mod_switch_to_inplace(one, enc_x_minus[i].parms_id());
-            evaluator.sub_plain_inplace(enc_x_minus[i], one);
-        }
-    }
-    Ciphertext pack_exp = exp_ct(moai_fused::pack(enc_x_minus, context), encoder, evaluator, relin_keys);
-    vector<Ciphertext> exp_x;
-    moai_fused::unpack(pack_exp, context, exp_x);
-    for (int i = 0; i < num; ++i)
-    {
-        vector<double> m = mask_vector(i, num, input_num, num_batch, bias_vec, 1.0);
-        Plaintext one;
-        if (m.empty())
-            encoder.encode(0, exp_x[i].scale(), one);
-        else
-            encoder.encode(m, exp_x[i].scale(), one);
-        evaluator.mod_switch_to_inplace(one, exp_x[i].parms_id());
-        evaluator.multiply_plain_inplace(exp_x[i], one);
-    }
-    Ciphertext pack_masked = moai_fused::pack(exp_x, context);
-    evaluator.rescale_to_next_inplace(pack_masked);
-    pack_masked.scale() = scale;
-    moai_fused::unpack(pack_masked, context, exp_x);
-    Ciphertext sum_exp_x = exp_x[0];
-    for (int i = 1; i < num; ++i) evaluator.add_inplace(sum_exp_x, exp_x[i]);
-    Plaintext eps;
-    encoder.encode(0.00001, sum_exp_x.parms_id(), sum_exp_x.scale(), eps);
-    evaluator.add_plain_inplace(sum_exp_x, eps);
-    sum_exp_x.scale() = scale;
-    while (context.get_context_data(sum_exp_x.parms_id())->chain_index() != 0) evaluator.mod_switch_to_next_inplace(sum_exp_x);
-    Ciphertext rtn;
-    boot.bootstrap_3(rtn, sum_exp_x);
-    while (context.get_context_data(rtn.parms_id())->chain_index() > (size_t)(iter + 1 + 3)) evaluator.mod_switch_to_next_inplace(rtn);
-    Ciphertext inv_sum = inverse_ct(rtn, encoder, evaluator, relin_keys, iter);
-    inv_sum.scale() = scale;
-    if (context.get_context_data(pack_masked.parms_id())->chain_index() < context.get_context_data(inv_sum.parms_id())->chain_index())
-        evaluator.mod_switch_to_inplace(inv_sum, pack_masked.parms_id());
-    if (context.get_context_data(pack_masked.parms_id())->chain_index() > context.get_context_data(inv_sum.parms_id())->chain_index())
-        evaluator.mod_switch_to_inplace(pack_masked, inv_sum.parms_id());
-    Ciphertext pack_inv = moai_fused::pack(vector<Ciphertext>(num, inv_sum), context), pack_out;
-    evaluator.multiply(pack_masked, pack_inv, pack_out);
-    evaluator.relinearize_inplace(pack_out, relin_keys);
-    evaluator.rescale_to_next_inplace(pack_out);
-    pack_out.scale() = scale;
-    vector<Ciphertext> out;
-    moai_fused::unpack(pack_out, context, out);
-    return out;
 }
 
 int main(int argc, char **argv)
@@ -235,25 +94,13 @@ int main(int argc, char **argv)
     vector<int> b_vec(slots, 0);
     for (size_t s = 0; s < (size_t)num_batch * num_input; s++) b_vec[s] = 1;
 
-    // bootstrapper with stand-in constants
-    const int p3 = logn / 3, totlen = (1 << p3) - 1, slotlen = 1 << logn;
-    auto random_set = [&](int count) {
-        vector<vector<complex<double>>> c(count, vector<complex<double>>(slotlen));
-        for (auto &d : c)
-            for (auto &z : d) z = { ud(rng) * 0.1, ud(rng) * 0.1 };
-        return c;
-    };
-    moai_fused::BootDiagonals3 dg;
-    dg.invfftcoeff1 = random_set(2 * totlen + 1);
-    dg.invfftcoeff2 = random_set(2 * totlen + 1);
-    dg.invfftcoeff3 = random_set(2 * totlen + 1);
-    dg.fftcoeff1 = random_set(2 * totlen + 1);
-    dg.fftcoeff2 = random_set(2 * totlen + 1);
-    dg.fftcoeff3 = random_set(2 * totlen + 1);
-    const double two_pi = 2 * M_PI;
-    moai_fused::ModularReducer3 reducer(
-        moai_fused::chebyshev_interpolant([=](double t) { return cos(two_pi * (25 * t - 0.25) / 4.0); }, 59, 4 * 59), 1 / two_pi, 2);
-    moai_fused::PackedBootstrapper3 boot(context, encoder, evaluator, relin_keys, gal_keys_boot, logn, logn, scale, dg, reducer);
+    // the Bootstrapper exactly as MOAI's driver sets it up (test_full_scheme.hpp:413-448), with the real constants
+    Decryptor decryptor(context, sk);
+    Bootstrapper bootstrapper(10, logn, 15, 34, scale, 25, 59, 2, 1, context, keygen, encoder, encryptor, decryptor, evaluator, relin_keys,
+                              gal_keys_boot);
+    bootstrapper.prepare_mod_polynomial();
+    bootstrapper.slot_vec.push_back(logn);
+    bootstrapper.generate_LT_coefficient_3();
 
     // one bootstrapping round: every ciphertext to the lowest level (:642-646), then bootstrap_3 in packs of boot_B
     auto bootstrap_round = [&](vector<Ciphertext> &cts, const char *name) {
@@ -273,7 +120,7 @@ int main(int argc, char **argv)
                 while (context.get_context_data(c.parms_id())->chain_index() != 0) evaluator.mod_switch_to_next_inplace(c);
             }
             Ciphertext packed = moai_fused::pack(part, context), res;
-            boot.bootstrap_3(res, packed);
+            bootstrapper.bootstrap_full_3(res, packed);
             vector<Ciphertext> un;
             moai_fused::unpack(res, context, un);
             for (int b = 0; b < B; b++)
@@ -376,7 +223,7 @@ int main(int argc, char **argv)
             context.sync();
             t_qk += now_s() - t1;
             t1 = now_s();
-            vector<Ciphertext> sm = softmax_boot_packed(QK, b_vec, num_input, context, encoder, evaluator, relin_keys, iter, boot, 7.5);
+            vector<Ciphertext> sm = softmax_boot(QK, b_vec, num_input, context, relin_keys, iter, sk, bootstrapper, 0); // softmax.hpp:308, unchanged
             context.sync();
             t_sm += now_s() - t1;
             t1 = now_s();

@@ -32,7 +32,9 @@ struct alignas(16) PrimeConst
     uint64_t qd;       // bit pattern of (double) q          } FP64 arithmetic modes (modarith.hip.h),
     uint64_t qinv;     // bit pattern of RN(1.0 / q)         } meaningful when fp_mode != 0
     uint64_t fp_mode;  // 0: integer only; M_FPN or M_FPR
-    uint64_t pad[5];
+    uint64_t nq;       // 2^64 - q     } M_LAZY8 (modarith.hip.h): stored, not derived on the device, so that the compiler
+    uint64_t n4q;      // 2^64 - 4 q   } keeps  t * (-q)  a multiply-add chain instead of a 64-bit subtract
+    uint64_t pad[3];
 };
 
 // Row -> context-prime map passed by value to kernels (rows of one RNS polynomial).

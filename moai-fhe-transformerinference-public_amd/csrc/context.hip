@@ -209,6 +209,8 @@ static void build_prime(int logn, uint64_t q, uint64_t psi, Tw *fwd, Tw *inv, Pr
     memset(pc, 0, sizeof(*pc));
     pc->q = q;
     pc->q2 = q << 1;
+    pc->nq = 0 - q;
+    pc->n4q = 0 - (q << 2);
     {
         // floor(2^128 / q)
         u128 hi = ((u128)1 << 64);

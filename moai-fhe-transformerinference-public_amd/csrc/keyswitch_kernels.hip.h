@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
         }
         else
         {
-            LoadFp op;
+            LoadFp52 op;
             op.qd = pc->qd;
             op.qinv = pc->qinv;
-            fwd_strided_tile<LOGN, LoadFp, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+            fwd_strided_tile<LOGN, LoadFp52, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
         }
     }
     // digit J is canonical under prime J: it needs reducing only when that prime is the larger one
@@ -343,14 +343,14 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-                const double vx = fp_red(direct ? fp_from_u64(x[2 * c]) : u2d(x[2 * c]), qd, qinv);
-                const double vy = fp_red(direct ? fp_from_u64(x[2 * c + 1]) : u2d(x[2 * c + 1]), qd, qinv);
+                const double vx = fp_red(direct ? fp_from_u52(x[2 * c]) : u2d(x[2 * c]), qd, qinv);
+                const double vy = fp_red(direct ? fp_from_u52(x[2 * c + 1]) : u2d(x[2 * c + 1]), qd, qinv);
                 const ulonglong2 ka = k0[c];
                 const ulonglong2 kb = k1[c];
-                double s0 = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u64(ka.x), qd, qinv);
-                double s1 = u2d(lo0[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u64(ka.y), qd, qinv);
-                double s2 = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u64(kb.x), qd, qinv);
-                double s3 = u2d(lo1[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u64(kb.y), qd, qinv);
+                double s0 = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u52(ka.x), qd, qinv);
+                double s1 = u2d(lo0[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(ka.y), qd, qinv);
+                double s2 = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kb.x), qd, qinv);
+                double s3 = u2d(lo1[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(kb.y), qd, qinv);
                 if (MODE == M_FPR || ((J - j0) & 15u) == 15u)
                 {
                     // M_FPR: 2^52 / q may be as small as 2; M_FPN: sixteen terms of at most 0.9 q on top of q/2
@@ -439,7 +439,7 @@ struct LoadExpandLastFp
     uint64_t ql, half, q, cr1, fix, qd, qinv;
     __device__ __forceinline__ uint64_t operator()(uint64_t v) const
     {
-        return d2u(fp_red(fp_from_u64(barrett64(csub(v + half, ql), q, cr1) + fix), u2d(qd), u2d(qinv)));
+        return d2u(fp_red(fp_from_u52(barrett64(csub(v + half, ql), q, cr1) + fix), u2d(qd), u2d(qinv)));
     }
 };
 

@@ -94,6 +94,7 @@ __device__ __forceinline__ void ct_bfly_noguard(uint64_t &x, uint64_t &y, uint64
 // patterns of (double q, double RN(1/q)).
 enum
 {
+    M_LAZY8 = -2,  // integer, q < 2^60: approximate Shoup quotient, values below 8q, see ct_bfly_lazy8; plain forward NTT
     M_GUARD2 = -1, // integer, any q < 2^61: the guard of every SECOND stage only (values below 8q), plain forward NTT
     M_GUARD = 0,   // integer, reference discipline [0,4q)
     M_NOGUARD = 1, // integer, 36 q < 2^64
@@ -113,6 +114,13 @@ __device__ __forceinline__ uint64_t d2u(double d)
 __device__ __forceinline__ double fp_from_u64(uint64_t v)
 {
     return __builtin_fma((double)(uint32_t)(v >> 32), 4294967296.0, (double)(uint32_t)v);
+}
+// exact conversion of an integer below 2^52 in two cheap steps: its bits are the mantissa of 2^52 + v (an OR on the high
+// dword), and subtracting 2^52 is exact.  The key-switch kernels convert sixteen key residues and eight digits per
+// thread and digit this way (canonical residues of primes below 2^51) instead of with two v_cvt + one fma.
+__device__ __forceinline__ double fp_from_u52(uint64_t v)
+{
+    return u2d(v | 0x4330000000000000ull) - 4503599627370496.0;
 }
 // x - rint(x/q) q, |result| <= q/2 (+1): exact for integer |x| < 2^53
 __device__ __forceinline__ double fp_red(double x, double q, double qinv)
@@ -189,12 +197,75 @@ __device__ __forceinline__ void ct_bfly_guard2(uint64_t &x, uint64_t &y, uint64_
     y = u + q2 - v;
 }
 
+// ---- M_LAZY8: the integer butterfly with fewer instructions (q < 2^60) ----------------------------------------------
+// Instruction counts on gfx950 decide this kernel (PMC: the integer pipes are busy 85 % of the time), and the exact
+// Shoup product costs about 20 of the 31 VALU instructions of a butterfly: four partial products plus three register moves
+// and a 64-bit add for hi64(y * wq), two three-multiply low products, and a 64-bit subtract that lowers to a carry pair.
+// Here:
+//  * the quotient takes the two HIGH cross terms only:  t' = y1 q1 + hi32(y1 q0) + hi32(y0 q1)  (y = y1:y0, wq = q1:q0).
+//    The exact t = floor(y wq / 2^64) has  t - 2 <= t' <= t  (the dropped low parts of the two cross terms and hi32(y0 q0)
+//    sum to less than 3 * 2^32), so  r = y w - t' q  lies in [0, 4q) instead of [0, 2q): two mul_hi, one mad, one add;
+//  * r is ONE multiply-add chain modulo 2^64:  y0 w0 + t0 n0  in a 64-bit accumulator, the four cross products into its
+//    high word, with n = 2^64 - q read from the per-prime record (no subtract);
+//  * every stage guards  u = x - 4q if x >= 4q  by adding 2^64 - 4q and testing the sign (values stay below 8q < 2^63), so
+//    x' = u + r < 8q and y' = u + 4q - r in (0, 8q): the same residues as the reference's [0, 4q) discipline.
+// The pass that finishes the transform reduces below q with three such conditional subtractions.
+__device__ __forceinline__ uint64_t csub_sign(uint64_t x, uint64_t neg_m)
+{
+    // x - m if x >= m else x, for x < 2^63 and m <= 2^62, given 2^64 - m
+    uint64_t d = x + neg_m;
+    return (int64_t)d < 0 ? x : d;
+}
+__device__ __forceinline__ uint64_t mul_shoup_approx(uint64_t y, uint64_t w, uint64_t wq, uint64_t nq)
+{
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint32_t q0 = (uint32_t)wq, q1 = (uint32_t)(wq >> 32);
+    uint64_t t = (uint64_t)y1 * q1 + __umulhi(y1, q0);
+    t += __umulhi(y0, q1);
+    const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32);
+    const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
+    uint64_t p = (uint64_t)y0 * w0;
+    p += (uint64_t)t0 * n0;
+    const uint32_t hi = (uint32_t)(p >> 32) + y0 * w1 + y1 * w0 + t0 * n1 + t1 * n0;
+    return ((uint64_t)hi << 32) | (uint32_t)p;
+}
+// x, y below 8q -> below 8q; nq = 2^64 - q, n4q = 2^64 - 4q
+__device__ __forceinline__ void ct_bfly_lazy8(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t nq, uint64_t n4q)
+{
+    const uint64_t u = csub_sign(x, n4q);
+    const uint64_t v = mul_shoup_approx(y, w, wq, nq);
+    x = u + v;
+    y = u - (v + n4q);
+}
+
+// Gentleman-Sande counterparts: x, y below 4q -> below 4q (the sum is guarded, the difference goes through the product,
+// which accepts any 64-bit operand); the last stage folds N^-1 in and needs no guard at all
+__device__ __forceinline__ void gs_bfly_lazy8(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t nq, uint64_t n4q)
+{
+    const uint64_t u = x, v = y;
+    x = csub_sign(u + v, n4q);
+    y = mul_shoup_approx(u - (v + n4q), w, wq, nq);
+}
+__device__ __forceinline__ void gs_bfly_last_lazy8(uint64_t &x, uint64_t &y, const Tw &ninv, const Tw &ninv_w1, uint64_t nq, uint64_t n4q)
+{
+    const uint64_t u = x, v = y;
+    x = mul_shoup_approx(u + v, ninv.w, ninv.wq, nq);
+    y = mul_shoup_approx(u - (v + n4q), ninv_w1.w, ninv_w1.wq, nq);
+}
+template <bool LZ>
+__device__ __forceinline__ void gs_bfly_sel(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t a, uint64_t b);
+
 // STAGES_LEFT = number of stages after this one (compile-time in the unrolled tiles): M_GUARD2 guards the stages
 // with an even number left, so the last stage of a transform is guarded and hands over values below 6q
 template <int MODE, int STAGES_LEFT = 0>
 __device__ __forceinline__ void ct_bfly_t(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t q, uint64_t q2)
 {
-    if (MODE == M_GUARD2)
+    if (MODE == M_LAZY8)
+    {
+        ct_bfly_lazy8(x, y, w, wq, q, q2); // (q, q2) carry (2^64 - q, 2^64 - 4q)
+    }
+    else if (MODE == M_GUARD2)
     {
         ct_bfly_guard2<(STAGES_LEFT % 2) == 0>(x, y, w, wq, q, q2);
     }
@@ -233,6 +304,18 @@ __device__ __forceinline__ void gs_bfly_last(uint64_t &x, uint64_t &y, const Tw 
     uint64_t v = y;
     x = mul_shoup_lazy(csub(u + v, q2), ninv.w, ninv.wq, q);
     y = mul_shoup_lazy(u + q2 - v, ninv_w1.w, ninv_w1.wq, q);
+}
+
+// (a, b) = (q, 2q) for the exact butterflies, (2^64 - q, 2^64 - 4q) for the M_LAZY8 ones
+template <>
+__device__ __forceinline__ void gs_bfly_sel<false>(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t a, uint64_t b)
+{
+    gs_bfly(x, y, w, wq, a, b);
+}
+template <>
+__device__ __forceinline__ void gs_bfly_sel<true>(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t a, uint64_t b)
+{
+    gs_bfly_lazy8(x, y, w, wq, a, b);
 }
 
 } // namespace moai

@@ -62,7 +62,29 @@ static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
         }
         switch (mode)
         {
-        case M_GUARD: launch_fwd_mode<LOGN, M_GUARD2>(c, a, s); break; // same residues, half the guards (modarith.hip.h)
+        case M_GUARD:
+        {
+            // integer primes: below 2^60 the butterfly with the approximate Shoup quotient (M_LAZY8), else the exact one with a
+            // guard every second stage (M_GUARD2); same residues either way (modarith.hip.h).  One launch pair per class.
+            static const long lazy8 = env_long("MOAI_NTT_LAZY8", 1);
+            NttArgs lo = a, hi = a;
+            lo.Lsel = hi.Lsel = 0;
+            for (uint32_t i = 0; i < a.Lsel; ++i)
+            {
+                NttArgs &dst = (lazy8 && c->primes[a.selp.idx[i]] < (1ull << 60)) ? lo : hi;
+                dst.selp.idx[dst.Lsel] = a.selp.idx[i];
+                dst.sel.idx[dst.Lsel++] = a.sel.idx[i];
+            }
+            if (lo.Lsel)
+            {
+                launch_fwd_mode<LOGN, M_LAZY8>(c, lo, s);
+            }
+            if (hi.Lsel)
+            {
+                launch_fwd_mode<LOGN, M_GUARD2>(c, hi, s);
+            }
+            break;
+        }
         case M_NOGUARD: launch_fwd_mode<LOGN, M_NOGUARD>(c, a, s); break;
         case M_FPN: launch_fwd_mode<LOGN, M_FPN>(c, a, s); break;
         default: launch_fwd_mode<LOGN, M_FPR>(c, a, s); break;
@@ -70,14 +92,33 @@ static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
     }
 }
 
+// inverse transform: rows of primes below 2^60 take the butterflies with the approximate Shoup quotient (M_LAZY8,
+// modarith.hip.h), the others the exact ones; one pair of launches per class, same residues
 template <int LOGN>
-static void launch_inv(const NttArgs &base, hipStream_t s)
+static void launch_inv(const moai_ctx *c, const NttArgs &base, hipStream_t s)
 {
-    NttArgs a = base;
+    static const long lazy8 = env_long("MOAI_NTT_LAZY8", 1);
     constexpr uint32_t tpr = 1u << (LOGN - 12);
-    a.total_work = a.n_poly * a.L * tpr;
-    hipLaunchKernelGGL(ntt_inv_contig<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(ntt_inv_strided<LOGN>, dim3(a.total_work), dim3(256), 0, s, a);
+    NttArgs lo = base, hi = base;
+    lo.Lsel = hi.Lsel = 0;
+    for (uint32_t r = 0; r < base.L; ++r)
+    {
+        NttArgs &dst = (lazy8 && c->primes[base.rows.idx[r]] < (1ull << 60)) ? lo : hi;
+        dst.selp.idx[dst.Lsel] = base.rows.idx[r];
+        dst.sel.idx[dst.Lsel++] = (uint16_t)r;
+    }
+    if (lo.Lsel)
+    {
+        lo.total_work = lo.n_poly * lo.Lsel * tpr;
+        hipLaunchKernelGGL((ntt_inv_contig<LOGN, true>), dim3(lo.total_work), dim3(256), 0, s, lo);
+        hipLaunchKernelGGL((ntt_inv_strided<LOGN, true>), dim3(lo.total_work), dim3(256), 0, s, lo);
+    }
+    if (hi.Lsel)
+    {
+        hi.total_work = hi.n_poly * hi.Lsel * tpr;
+        hipLaunchKernelGGL((ntt_inv_contig<LOGN, false>), dim3(hi.total_work), dim3(256), 0, s, hi);
+        hipLaunchKernelGGL((ntt_inv_strided<LOGN, false>), dim3(hi.total_work), dim3(256), 0, s, hi);
+    }
 }
 
 } // namespace moai
@@ -284,7 +325,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     case LG:                            \
         if (inverse)                    \
         {                               \
-            launch_inv<LG>(a, s);       \
+            launch_inv<LG>(c, a, s);    \
         }                               \
         else                            \
         {                               \

@@ -89,12 +89,12 @@ struct NttArgs
 template <int MODE>
 __device__ __forceinline__ uint64_t mode_q(const PrimeConst &pc)
 {
-    return MODE >= M_FPN ? pc.qd : pc.q;
+    return MODE >= M_FPN ? pc.qd : (MODE == M_LAZY8 ? pc.nq : pc.q);
 }
 template <int MODE>
 __device__ __forceinline__ uint64_t mode_q2(const PrimeConst &pc)
 {
-    return MODE >= M_FPN ? pc.qinv : pc.q2;
+    return MODE >= M_FPN ? pc.qinv : (MODE == M_LAZY8 ? pc.n4q : pc.q2);
 }
 
 // =====================================================================================================
@@ -130,13 +130,23 @@ struct LoadFp
     }
 };
 
+// the same for an integer known to be below 2^52 (a key-switch digit canonical under a prime below 2^52)
+struct LoadFp52
+{
+    uint64_t qd, qinv;
+    __device__ __forceinline__ uint64_t operator()(uint64_t v) const
+    {
+        return d2u(fp_red(fp_from_u52(v), u2d(qd), u2d(qinv)));
+    }
+};
+
 // the same for integers of any size (a key-switch digit under a 52..61-bit prime): integer Barrett step first
 struct LoadBarrettFp
 {
     uint64_t q, cr1, qd, qinv;
     __device__ __forceinline__ uint64_t operator()(uint64_t v) const
     {
-        return d2u(fp_red(fp_from_u64(barrett64(v, q, cr1)), u2d(qd), u2d(qinv)));
+        return d2u(fp_red(fp_from_u52(barrett64(v, q, cr1)), u2d(qd), u2d(qinv))); // reduced below q < 2^51
     }
 };
 
@@ -249,7 +259,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
 // five waves per SIMD (96 VGPRs) where the body fits; the modes whose body does not (12, 8 and 14 spilled registers
 // under that cap) run faster at four: M_GUARD2 12.17 -> 11.90 ms per batch transform, FP64 / unguarded rows 2-3 %
 template <int LOGN, int MODE = M_GUARD>
-__global__ __launch_bounds__(256, (MODE == M_GUARD2 || MODE == M_FPR || MODE == M_NOGUARD) ? 4 : 5) void ntt_fwd_strided(NttArgs a)
+__global__ __launch_bounds__(256, (MODE == M_GUARD2 || MODE == M_LAZY8 || MODE == M_FPR || MODE == M_NOGUARD) ? 4 : 5) void ntt_fwd_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
@@ -272,7 +282,8 @@ __global__ __launch_bounds__(256, (MODE == M_GUARD2 || MODE == M_FPR || MODE == 
     }
     else
     {
-        fwd_strided_tile<LOGN, LoadIdentity, MODE>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), pc.q, pc.q2, lds, threadIdx.x);
+        fwd_strided_tile<LOGN, LoadIdentity, MODE>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), mode_q<MODE>(pc), mode_q2<MODE>(pc), lds,
+                                                   threadIdx.x);
     }
 }
 
@@ -370,6 +381,13 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
             v.x = barrett64(x[2 * c], q, cr1);
             v.y = barrett64(x[2 * c + 1], q, cr1);
         }
+        else if (MODE == M_LAZY8)
+        {
+            // values below 8q; (q, q2) = (2^64 - q, 2^64 - 4q), and 2^64 - 2q = (2^64 - 4q) / 2 + 2^63
+            const uint64_t n2q = (q2 >> 1) | 0x8000000000000000ull;
+            v.x = csub_sign(csub_sign(csub_sign(x[2 * c], q2), n2q), q);
+            v.y = csub_sign(csub_sign(csub_sign(x[2 * c + 1], q2), n2q), q);
+        }
         else if (MODE == M_GUARD2)
         {
             // the last stage is a guarded one: values below 6q
@@ -425,7 +443,8 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 // =====================================================================================================
 // inverse, contiguous pass: stages LOGN-1 .. LOGN-8 (gap 1 .. 128); lazy [0,2q) out
 // =====================================================================================================
-template <int LOGN>
+// LZ: the M_LAZY8 butterflies (modarith.hip.h), with (q, q2) = (2^64 - q, 2^64 - 4q); values below 4q instead of 2q
+template <int LOGN, bool LZ = false>
 __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
                                                 const Tw *__restrict__ twb)
@@ -477,7 +496,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
             if (!(j & half))
             {
                 Tw t = tb[(1 << (u - 4)) - 1 + (j >> (8 - u))];
-                gs_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -506,7 +525,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
             if (!(j & half))
             {
                 Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
-                gs_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -517,7 +536,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
     }
 }
 
-template <int LOGN>
+template <int LOGN, bool LZ = false>
 __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -526,17 +545,17 @@ __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
     const uint32_t pol = w % a.n_poly;
     const uint32_t rest = w / a.n_poly;
     const uint32_t tile = rest % TPR;
-    const uint32_t r = rest / TPR;
-    const uint32_t prime = a.rows.idx[r];
-    inv_contig_tile<LOGN>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
-                          a.pc[prime].q, a.pc[prime].q2, lds2, threadIdx.x,
-                          a.twb + (size_t)prime * ((size_t)TPR * 15 * 256));
+    const uint32_t r = __builtin_amdgcn_readfirstlane(a.sel.idx[rest / TPR]);
+    const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[rest / TPR]);
+    const PrimeConst &pc = a.pc[prime];
+    inv_contig_tile<LOGN, LZ>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN), LZ ? pc.nq : pc.q,
+                              LZ ? pc.n4q : pc.q2, lds2, threadIdx.x, a.twb + (size_t)prime * ((size_t)TPR * 15 * 256));
 }
 
 // =====================================================================================================
 // inverse, strided pass: stages LOGN-9 .. 0, N^-1 folded into stage 0; writes canonical
 // =====================================================================================================
-template <int LOGN>
+template <int LOGN, bool LZ = false>
 __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                  const PrimeConst *pc, uint64_t *lds, const uint32_t tid)
 {
@@ -544,8 +563,8 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
     constexpr int RB = R1 - 4;
     constexpr int GB = 12 - R1;
     constexpr uint32_t G = 1u << GB;
-    const uint64_t q = pc->q;
-    const uint64_t q2 = pc->q2;
+    const uint64_t q = LZ ? pc->nq : pc->q;
+    const uint64_t q2 = LZ ? pc->n4q : pc->q2;
     uint64_t *__restrict__ row = rowp + tile * G;
 
     uint64_t x[16];
@@ -570,7 +589,7 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
                 {
                     uint32_t t_ = (th << 4) | (uint32_t)j;
                     Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
-                    gs_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                    gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
                 }
             }
         }
@@ -605,7 +624,7 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
             if (!(j & half))
             {
                 Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
-                gs_bfly(x[j], x[j + half], t.w, t.wq, q, q2);
+                gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
             }
         }
     }
@@ -615,27 +634,38 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
 #pragma unroll
         for (int j = 0; j < 8; ++j)
         {
-            gs_bfly_last(x[j], x[j + 8], ninv, ninv_w1, q, q2);
+            if (LZ)
+            {
+                gs_bfly_last_lazy8(x[j], x[j + 8], ninv, ninv_w1, q, q2);
+            }
+            else
+            {
+                gs_bfly_last(x[j], x[j + 8], ninv, ninv_w1, q, q2);
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {
         uint32_t e = (uint32_t)j * 256u + tid;
-        row[((e >> GB) << 8) + (e & (G - 1))] = csub(x[j], q);
+        // exact: below 2q; LZ: below 4q, with 2^64 - 2q = (2^64 - 4q) / 2 + 2^63
+        row[((e >> GB) << 8) + (e & (G - 1))] = LZ ? csub_sign(csub_sign(x[j], (q2 >> 1) | 0x8000000000000000ull), q) : csub(x[j], q);
     }
 }
 
-template <int LOGN>
-__global__ __launch_bounds__(256, 5) void ntt_inv_strided(NttArgs a)
+template <int LOGN, bool LZ = false>
+__global__ __launch_bounds__(256, LZ ? 4 : 5) void ntt_inv_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
     const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t tile = w % TPR;
-    const uint32_t prow = w / TPR;
-    const uint32_t prime = a.rows.idx[prow % a.L];
-    inv_strided_tile<LOGN>(a.data + ((size_t)prow << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc + prime, lds, threadIdx.x);
+    const uint32_t srow = w / TPR; // over n_poly * Lsel selected rows
+    const uint32_t si = srow % a.Lsel;
+    const uint32_t r = __builtin_amdgcn_readfirstlane(a.sel.idx[si]);
+    const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[si]);
+    inv_strided_tile<LOGN, LZ>(a.data + ((size_t)((srow / a.Lsel) * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc + prime, lds,
+                               threadIdx.x);
 }
 
 // =====================================================================================================

@@ -258,6 +258,24 @@ int moai_ckks_tables(moai_ctx *ctx, uint32_t *index_map, double *inv_root_powers
  *   MOAI_KS_FP_MIN_ROWS  batch * L from which the key switch uses the FP64 arithmetic modes (default 16) */
 int moai_set_tuning(const char *name, long value);
 
+/* ---- hoisted rotations -------------------------------------------------------------------------------------------
+ * out[r] = apply_galois(in, galois_elts[r], galois_keys[r]) for r < R -- R calls of Evaluator::rotate_vector /
+ * apply_galois on the SAME ciphertext (SEAL/evaluator.cpp:2563-2665 over :2724-3020; the baby steps of MOAI's
+ * bootstrapping transforms, include/source/bootstrapping/Bootstrapper.cpp:2017-2022, 2082-2088) -- with ONE digit
+ * decomposition (the l (l + 1) transforms of switch_key_inplace) shared by all of them.  Bit-identical to the R separate
+ * calls: the digit of a permuted polynomial is the permuted digit plus (q_J mod q_I) times the rotation's sign mask, and
+ * that second term is the per-(key, level) constant moai_hoist_correction computes once (csrc/keyswitch_kernels.hip.h
+ * has the derivation).  The identity needs INTT(c1) free of zero coefficients; the call checks that on the device and
+ * otherwise makes the R separate calls itself (*used_fallback = 1).
+ *   in, outs[r]  [batch][2][L][N] (no output may alias the input)   correction [2][L+1][N] (rows 0..L-1 under primes
+ *   0..L-1, row L under the special prime), computed for the same (key, galois_elt, L).  outs / galois_keys /
+ *   corrections: host arrays of R device pointers. */
+int moai_hoist_correction(moai_ctx *ctx, const uint64_t *galois_key, uint32_t galois_elt, size_t L, uint64_t *correction,
+                          void *stream);
+int moai_apply_galois_hoisted(moai_ctx *ctx, const uint64_t *in, uint64_t *const *outs, size_t L, const uint32_t *galois_elts,
+                              const uint64_t *const *galois_keys, const uint64_t *const *corrections, size_t R, size_t batch,
+                              int *used_fallback, void *stream);
+
 /* ---- operation census ----------------------------------------------------------------------------------------------
  * moai_op_trace(1) clears and starts, moai_op_trace(0) stops counting what the entry points above were asked to do:
  * per (entry point, level L) the sum of the call's own batch argument (polynomials for the element-wise and NTT calls,

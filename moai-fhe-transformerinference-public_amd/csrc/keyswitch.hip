@@ -18,6 +18,7 @@
 #include <mutex>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "launch.h"
 #include <vector>
@@ -1022,4 +1023,356 @@ extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, siz
         return rc;
     }
     return ntt_launch(c, out, P, L_out, rm, false, s);
+}
+
+// ---- hoisted rotations (keyswitch_kernels.hip.h explains the identity) --------------------------------------------
+namespace moai {
+
+template <int LOGN>
+static void hoist_contig_finish(moai_ctx *c, uint64_t *tmp, size_t L, size_t batch, const KsGroup &grp, size_t G, int mode, hipStream_t s)
+{
+    // the strided pass left [B][G][L][N] in the mode's lazy form: the plain contiguous pass finishes every row of group
+    // member g under that member's prime and leaves canonical residues
+    constexpr uint32_t tpr = 1u << (LOGN - 12);
+    for (size_t g = 0; g < G; ++g)
+    {
+        NttArgs a;
+        memset(&a, 0, sizeof(a));
+        a.data = tmp;
+        a.tw = mode >= M_FPN ? c->fwd_twf : c->fwd_tw;
+        a.twb = mode >= M_FPN ? c->fwd_twfb : c->fwd_twb;
+        a.pc = c->pc;
+        a.L = (uint32_t)(G * L);
+        a.n_poly = (uint32_t)batch;
+        a.Lsel = 0;
+        for (size_t J = 0; J < L; ++J)
+        {
+            if (grp.slot[g] == J)
+            {
+                continue; // the strided pass skipped it: the digit under its own prime is read from the ciphertext
+            }
+            a.sel.idx[a.Lsel] = (uint16_t)(g * L + J);
+            a.selp.idx[a.Lsel++] = grp.prime[g];
+        }
+        a.total_work = a.n_poly * a.Lsel * tpr;
+        switch (mode)
+        {
+        case M_FPN: hipLaunchKernelGGL((ntt_fwd_contig<LOGN, M_FPN>), dim3(a.total_work), dim3(256), 0, s, a); break;
+        case M_FPR: hipLaunchKernelGGL((ntt_fwd_contig<LOGN, M_FPR>), dim3(a.total_work), dim3(256), 0, s, a); break;
+        case M_NOGUARD: hipLaunchKernelGGL((ntt_fwd_contig<LOGN, M_NOGUARD>), dim3(a.total_work), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((ntt_fwd_contig<LOGN, M_GUARD>), dim3(a.total_work), dim3(256), 0, s, a); break;
+        }
+    }
+}
+
+template <int LOGN>
+static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *in, size_t L, size_t batch, const KsGroup &grp,
+                       size_t G, int mode, const uint32_t *const *tables, const uint64_t *const *keys, const uint64_t *const *corrs,
+                       uint64_t *acc, size_t acc_stride_words, size_t R, hipStream_t s)
+{
+    constexpr uint32_t TPR = 1u << (LOGN - 12);
+    KsP1Args p1;
+    p1.t = t;
+    p1.tmp = tmp;
+    p1.tw = mode >= M_FPN ? c->fwd_twf : c->fwd_tw;
+    p1.pc = c->pc;
+    p1.grp = grp;
+    p1.L = (uint32_t)L;
+    p1.G = (uint32_t)G;
+    p1.total_work = (uint32_t)(batch * G * L * TPR);
+    switch (mode)
+    {
+    case M_FPN: hipLaunchKernelGGL((ks_fwd_strided<LOGN, M_FPN>), dim3(p1.total_work), dim3(256), 0, s, p1); break;
+    case M_FPR: hipLaunchKernelGGL((ks_fwd_strided<LOGN, M_FPR>), dim3(p1.total_work), dim3(256), 0, s, p1); break;
+    case M_NOGUARD: hipLaunchKernelGGL((ks_fwd_strided<LOGN, M_NOGUARD>), dim3(p1.total_work), dim3(256), 0, s, p1); break;
+    default: hipLaunchKernelGGL((ks_fwd_strided<LOGN, M_GUARD>), dim3(p1.total_work), dim3(256), 0, s, p1); break;
+    }
+    MOAI_LAUNCH_CHECK();
+    hoist_contig_finish<LOGN>(c, tmp, L, batch, grp, G, mode, s);
+    MOAI_LAUNCH_CHECK();
+    for (size_t r = 0; r < R; ++r)
+    {
+        HoistMacArgs m;
+        m.dig = tmp;
+        m.ct = in;
+        m.table = tables[r];
+        m.key = keys[r];
+        m.corr = corrs[r];
+        m.acc = acc + r * acc_stride_words;
+        m.pc = c->pc;
+        m.grp = grp;
+        m.L = (uint32_t)L;
+        m.G = (uint32_t)G;
+        m.k = (uint32_t)c->k;
+        m.B = (uint32_t)batch;
+        m.total_work = (uint32_t)(batch * G * TPR * 2);
+        if (mode == M_FPN)
+        {
+            hipLaunchKernelGGL((ks_hoisted_mac<LOGN, true, false>), dim3(m.total_work), dim3(256), 0, s, m);
+        }
+        else if (mode == M_FPR)
+        {
+            hipLaunchKernelGGL((ks_hoisted_mac<LOGN, true, true>), dim3(m.total_work), dim3(256), 0, s, m);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ks_hoisted_mac<LOGN, false, false>), dim3(m.total_work), dim3(256), 0, s, m);
+        }
+    }
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+} // namespace moai
+
+extern "C" int moai_hoist_correction(moai_ctx *c, const uint64_t *galois_key, uint32_t galois_elt, size_t L, uint64_t *correction,
+                                     void *stream)
+{
+    trace_op("hoist_correction", L, 1);
+    int rc = check_level(c, L, 2);
+    if (rc)
+    {
+        return rc;
+    }
+    if (!galois_key || !correction)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    if (c->k < 2 || L > c->k - 1)
+    {
+        return set_error(MOAI_EINVAL, "L exceeds the key's decomposition size");
+    }
+    if (!(galois_elt & 1u) || galois_elt >= 2 * c->n)
+    {
+        return set_error(MOAI_EINVAL, "Galois element is not valid");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
+    void *wsp;
+    rc = workspace(c, align256((L + 1) * row_bytes), s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    uint64_t *mask = static_cast<uint64_t *>(wsp);
+    hipLaunchKernelGGL(galois_sign_mask_kernel, dim3((uint32_t)((c->n + 255) / 256)), dim3(256), 0, s, mask, (uint32_t)c->logn, galois_elt,
+                       (uint32_t)(L + 1));
+    MOAI_LAUNCH_CHECK();
+    std::vector<uint32_t> pidx(L + 1);
+    for (size_t i = 0; i < L; ++i)
+    {
+        pidx[i] = (uint32_t)i;
+    }
+    pidx[L] = (uint32_t)(c->k - 1);
+    RowMap rm;
+    rc = make_rowmap(c, L + 1, pidx.data(), &rm);
+    if (rc)
+    {
+        return rc;
+    }
+    rc = ntt_launch(c, mask, 1, L + 1, rm, false, s);
+    if (rc)
+    {
+        return rc;
+    }
+    HoistCorrArgs g;
+    g.key = galois_key;
+    g.mask = mask;
+    g.out = correction;
+    g.pc = c->pc;
+    g.L = (uint32_t)L;
+    g.k = (uint32_t)c->k;
+    g.n2 = (uint32_t)(c->n >> 1);
+    MOAI_CHECK_GRID_ROWS(2 * (L + 1));
+    hipLaunchKernelGGL(ks_hoist_correction_kernel, rgrid(c, 2 * (L + 1)), dim3(256), 0, s, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64_t *const *outs, size_t L, const uint32_t *galois_elts,
+                                         const uint64_t *const *galois_keys, const uint64_t *const *corrections, size_t R, size_t batch,
+                                         int *used_fallback, void *stream)
+{
+    trace_op("apply_galois_hoisted", L, batch * R);
+    if (used_fallback)
+    {
+        *used_fallback = 0;
+    }
+    int rc = check_level(c, L, batch * 2);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0 || R == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!in || !outs || !galois_elts || !galois_keys || !corrections)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    const size_t n = c->n, k = c->k;
+    if (k < 2)
+    {
+        return set_error(MOAI_ELOGIC, "keyswitching is not supported by the context");
+    }
+    if (L > k - 1)
+    {
+        return set_error(MOAI_EINVAL, "L exceeds the key's decomposition size");
+    }
+    if (R > 64)
+    {
+        return set_error(MOAI_EINVAL, "at most 64 rotations per call");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<const uint32_t *> tables(R);
+    for (size_t r = 0; r < R; ++r)
+    {
+        if (!galois_keys[r] || !corrections[r] || !outs[r] || outs[r] == in)
+        {
+            return set_error(MOAI_EINVAL, "null key, correction or output (an output must not be the input)");
+        }
+        rc = galois_table(c, galois_elts[r], s, &tables[r]);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    bool fallback = c->logn < 12;
+    if (!fallback)
+    {
+        const size_t row_bytes = n * sizeof(uint64_t);
+        const size_t G = ks_group_size(c, L, batch);
+        const size_t sz_t = align256(batch * L * row_bytes);
+        const size_t sz_tmp = align256(batch * G * L * row_bytes);
+        const size_t acc_stride_words = batch * 2 * (L + 1) * n;
+        const size_t sz_acc = align256(R * acc_stride_words * sizeof(uint64_t));
+        const size_t sz_last = align256(batch * 2 * row_bytes);
+        const size_t sz_u = align256(2 * batch * L * row_bytes);
+        const size_t sz_c0 = align256(batch * 2 * L * row_bytes);
+        std::unique_lock<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
+        void *wsp;
+        rc = workspace(c, 256 + sz_t + sz_tmp + sz_acc + sz_last + sz_u + sz_c0, s, &wsp);
+        if (rc)
+        {
+            return rc;
+        }
+        char *base = static_cast<char *>(wsp);
+        uint32_t *flag = reinterpret_cast<uint32_t *>(base);
+        uint64_t *t = reinterpret_cast<uint64_t *>(base + 256);
+        uint64_t *tmp = reinterpret_cast<uint64_t *>(base + 256 + sz_t);
+        uint64_t *acc = reinterpret_cast<uint64_t *>(base + 256 + sz_t + sz_tmp);
+        uint64_t *last = reinterpret_cast<uint64_t *>(base + 256 + sz_t + sz_tmp + sz_acc);
+        uint64_t *u = reinterpret_cast<uint64_t *>(base + 256 + sz_t + sz_tmp + sz_acc + sz_last);
+        uint64_t *pc0 = reinterpret_cast<uint64_t *>(base + 256 + sz_t + sz_tmp + sz_acc + sz_last + sz_u);
+        const uint32_t n2 = (uint32_t)(n >> 1);
+        // t = INTT(c1), UNPERMUTED: once for all rotations
+        MOAI_CHECK_GRID_ROWS(batch * L);
+        hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, in, t, (uint32_t)L, (uint32_t)(2 * L), (uint32_t)L, NO_ZERO, n2);
+        MOAI_LAUNCH_CHECK();
+        RowMap rm;
+        rc = make_rowmap(c, L, nullptr, &rm);
+        if (rc)
+        {
+            return rc;
+        }
+        rc = ntt_launch(c, t, batch, L, rm, true, s);
+        if (rc)
+        {
+            return rc;
+        }
+        MOAI_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(any_zero_kernel, dim3(1024), dim3(256), 0, s, t, batch * L * n / 2, flag);
+        MOAI_LAUNCH_CHECK();
+        uint32_t host_flag = 0;
+        MOAI_HIP_CHECK(hipMemcpyAsync(&host_flag, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MOAI_HIP_CHECK(hipStreamSynchronize(s));
+        if (host_flag)
+        {
+            fallback = true; // a zero coefficient: the identity above does not hold for it
+        }
+        else
+        {
+            const bool allow_fp = (long)(batch * L) >= tuning("MOAI_KS_FP_MIN_ROWS", 16);
+            std::vector<uint16_t> order;
+            std::vector<int> order_mode;
+            for (int mode = M_FPR; mode >= M_GUARD; --mode)
+            {
+                for (size_t Iidx = 0; Iidx <= L; ++Iidx)
+                {
+                    const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+                    if (ks_mode(c, prime, L, allow_fp) == mode)
+                    {
+                        order.push_back((uint16_t)Iidx);
+                        order_mode.push_back(mode);
+                    }
+                }
+            }
+            for (size_t o0 = 0; o0 < order.size();)
+            {
+                const int mode = order_mode[o0];
+                size_t g = 0;
+                while (o0 + g < order.size() && g < G && order_mode[o0 + g] == mode)
+                {
+                    ++g;
+                }
+                KsGroup grp;
+                for (size_t i = 0; i < MOAI_MAX_RNS; ++i)
+                {
+                    size_t Iidx = order[o0 + (i < g ? i : 0)];
+                    grp.prime[i] = (uint16_t)(Iidx == L ? k - 1 : Iidx);
+                    grp.slot[i] = (uint16_t)Iidx;
+                }
+                switch (c->logn)
+                {
+                case 12: rc = hoist_group<12>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 13: rc = hoist_group<13>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 14: rc = hoist_group<14>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 15: rc = hoist_group<15>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                default: rc = hoist_group<16>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                }
+                if (rc)
+                {
+                    return rc;
+                }
+                o0 += g;
+            }
+            // per rotation: the permuted c0 is the addend, then the shared mod-down tail (evaluator.cpp:2913-3018)
+            for (size_t r = 0; r < R; ++r)
+            {
+                uint64_t *acc_r = acc + r * acc_stride_words;
+                // pc0 [B][2][L][N] = perm(in): polynomial 0 is the addend, polynomial 1 is not read (add_mode 2)
+                rc = moai_galois_permute(c, in, pc0, batch * 2, L, galois_elts[r], stream);
+                if (rc)
+                {
+                    return rc;
+                }
+                MOAI_CHECK_GRID_ROWS(batch * 2);
+                hipLaunchKernelGGL(sum_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc_r, last, (uint32_t)(L + 1), (uint32_t)L, 1u,
+                                   (size_t)0, c->pc, (uint32_t)(k - 1), n2);
+                MOAI_LAUNCH_CHECK();
+                rc = moddown(c, last, acc_r, (uint32_t)(L + 1), u, outs[r], batch * 2, L, (uint32_t)(k - 1), pc0, (uint32_t)(2 * L), 2, s);
+                if (rc)
+                {
+                    return rc;
+                }
+            }
+            return MOAI_OK;
+        }
+    }
+    // fallback: the reference's sequence per rotation
+    if (used_fallback)
+    {
+        *used_fallback = 1;
+    }
+    for (size_t r = 0; r < R; ++r)
+    {
+        rc = moai_apply_galois_to(c, in, outs[r], L, galois_elts[r], galois_keys[r], batch, stream);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    return MOAI_OK;
 }

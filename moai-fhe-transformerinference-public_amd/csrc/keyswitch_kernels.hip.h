@@ -419,6 +419,190 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
     }
 }
 
+// ---- hoisted rotations: several Galois automorphisms of ONE ciphertext share its digit decomposition --------------
+// rotate_vector(ct, step_r) for r = 1..R (the baby steps of MOAI's bootstrapping transforms, include/source/
+// bootstrapping/Bootstrapper.cpp:2017-2022, 2082-2088) is, per rotation, apply_galois_ntt on both polynomials and
+// switch_key_inplace on the permuted c1 (SEAL/evaluator.cpp:2631-2654, 2724-3020): l (l + 1) transforms each.  With
+// sigma the automorphism, t = INTT(c1) and s(j) its sign at output coefficient j, the digit SEAL transforms is
+//     [ sigma(t_J) ]_{q_I}(j) = [ t_J(pi j) ]_{q_I}                        where s(j) = +1
+//                             = [ q_J - t_J(pi j) ]_{q_I} = -[t_J(pi j)]_{q_I} + (q_J mod q_I)   where s(j) = -1, t_J(pi j) != 0
+// (also when q_J < q_I, where SEAL does not reduce: q_J - t = -t + q_J), i.e.
+//     [sigma(t_J)]_{q_I} = sigma([t_J]_{q_I}) + delta_{J,I} m      (mod q_I),   m(j) = 1 where s(j) = -1,
+// as long as no coefficient of t is zero.  NTT_I is linear and turns sigma into the index permutation
+// apply_galois_ntt uses, so with D_{J,I} = NTT_I([t_J]_{q_I}) computed ONCE
+//     acc_r[K][I] = sum_J perm_r(D_{J,I}) (*) key_r[J][K][I]  +  NTT_I(m_r) (*) sum_J delta_{J,I} key_r[J][K][I]
+// equals the reference's sum modulo q_I, and the canonical results are the same bits.  The second term depends on the
+// key and the level only ("correction", ks_hoist_correction_kernel).  A zero coefficient of t (probability 2^-46 each;
+// certain for transparent or test ciphertexts) falls back to the per-rotation path (host side).
+struct HoistCorrArgs
+{
+    const uint64_t *key;   // [k-1][2][k][N]
+    const uint64_t *mask;  // [L+1][N]: NTT of the sign mask under slot i's prime
+    uint64_t *out;         // [2][L+1][N]
+    const PrimeConst *pc;
+    uint32_t L, k, n2;
+};
+
+// out[K][slot] = mask[slot] (*) sum_{J < L} (q_J mod q_slot) key[J][K][slot]      blockIdx.y = K * (L + 1) + slot
+__global__ __launch_bounds__(256) void ks_hoist_correction_kernel(HoistCorrArgs g)
+{
+    const uint32_t K = blockIdx.y / (g.L + 1), slot = blockIdx.y % (g.L + 1);
+    const uint32_t prime = slot == g.L ? g.k - 1 : slot;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const ulonglong2 *mk = reinterpret_cast<const ulonglong2 *>(g.mask) + (size_t)slot * g.n2;
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.out) + ((size_t)K * (g.L + 1) + slot) * g.n2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < g.n2; j += gridDim.x * 256u)
+    {
+        uint64_t lx = 0, hx = 0, ly = 0, hy = 0;
+        for (uint32_t J = 0; J < g.L; ++J)
+        {
+            if (J == slot)
+            {
+                continue; // q_J mod q_J = 0: the digit under its own prime is the target row itself
+            }
+            const uint64_t delta = barrett64(g.pc[J].q, q, cr1);
+            const ulonglong2 kv = (reinterpret_cast<const ulonglong2 *>(g.key) + ((size_t)(J * 2 + K) * g.k + prime) * g.n2)[j];
+            mac128r(lx, hx, kv.x, delta);
+            mac128r(ly, hy, kv.y, delta);
+        }
+        const ulonglong2 m = mk[j];
+        ulonglong2 r;
+        r.x = mulmod_barrett(barrett128(lx, hx, q, cr0, cr1), m.x, q, cr0, cr1);
+        r.y = mulmod_barrett(barrett128(ly, hy, q, cr0, cr1), m.y, q, cr0, cr1);
+        o[j] = r;
+    }
+}
+
+// m[j] = 1 where x -> x^elt negates the coefficient that lands on j (GaloisTool::apply_galois, SEAL/util/galois.cpp:133-190)
+__global__ __launch_bounds__(256) void galois_sign_mask_kernel(uint64_t *m, uint32_t logn, uint32_t elt, uint32_t copies)
+{
+    const uint32_t n = 1u << logn;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n)
+    {
+        const uint32_t raw = (uint32_t)(((uint64_t)i * elt) & (2u * n - 1u));
+        const uint32_t j = raw & (n - 1u);
+        const uint64_t v = raw >> logn;
+        for (uint32_t c = 0; c < copies; ++c)
+        {
+            m[(size_t)c * n + j] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void any_zero_kernel(const uint64_t *v, size_t words2, uint32_t *flag)
+{
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(v);
+    bool z = false;
+    for (size_t j = (size_t)blockIdx.x * 256u + threadIdx.x; j < words2; j += (size_t)gridDim.x * 256u)
+    {
+        const ulonglong2 x = p[j];
+        z = z || x.x == 0 || x.y == 0;
+    }
+    if (z)
+    {
+        atomicOr(flag, 1u);
+    }
+}
+
+struct HoistMacArgs
+{
+    const uint64_t *dig;   // [B][G][L][N]: D_{J,I}, canonical, for the G output moduli of this launch
+    const uint64_t *ct;    // the UNPERMUTED input [B][2][L][N]: its c1 row J is the digit under prime J
+    const uint32_t *table; // NTT-domain index permutation of this rotation (galois_table)
+    const uint64_t *key;   // this rotation's key [k-1][2][k][N]
+    const uint64_t *corr;  // this rotation's correction [2][L+1][N]
+    uint64_t *acc;         // this rotation's [B][2][L+1][N]
+    const PrimeConst *pc;
+    KsGroup grp;
+    uint32_t L, G, k, B;
+    uint32_t total_work;
+};
+
+// acc[b][K][slot] = sum_J perm(D[b][g][J]) (*) key[J][K][prime] + corr[K][slot]; one workgroup = 2048 outputs of one (b, g)
+template <int LOGN, bool FP, bool FPR>
+__global__ __launch_bounds__(256, 4) void ks_hoisted_mac(HoistMacArgs a)
+{
+    constexpr uint32_t TPR8 = 1u << (LOGN - 11);
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t bq = w % a.B;
+    w /= a.B;
+    const uint32_t tile = w % TPR8;
+    const uint32_t g = w / TPR8;
+    const uint32_t prime = a.grp.prime[g];
+    const uint32_t slot = a.grp.slot[g];
+    const PrimeConst *pc = a.pc + prime;
+    const uint64_t q = pc->q;
+    uint32_t src[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+        src[e] = a.table[(tile << 11) + ((uint32_t)e << 8) + threadIdx.x];
+    }
+    const size_t obase = ((size_t)tile << 11) + threadIdx.x;
+    uint64_t lo0[8], hi0[8], lo1[8], hi1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+        lo0[e] = hi0[e] = lo1[e] = hi1[e] = 0;
+    }
+    const double qd = u2d(pc->qd), qinv = u2d(pc->qinv);
+    for (uint32_t J = 0; J < a.L; ++J)
+    {
+        const uint64_t *__restrict__ row = (slot == J) ? a.ct + (((size_t)(bq * 2 + 1) * a.L + J) << LOGN)
+                                                       : a.dig + ((((size_t)bq * a.G + g) * a.L + J) << LOGN);
+        const uint64_t *__restrict__ k0 = a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN) + obase;
+        const uint64_t *__restrict__ k1 = a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN) + obase;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+        {
+            const uint64_t x = row[src[e]];
+            const uint64_t ka = k0[(size_t)e << 8], kb = k1[(size_t)e << 8];
+            if (FP)
+            {
+                const double v = fp_red(fp_from_u52(x), qd, qinv);
+                double s0 = u2d(lo0[e]) + fp_mulmod_q(v, fp_from_u52(ka), qd, qinv);
+                double s1 = u2d(lo1[e]) + fp_mulmod_q(v, fp_from_u52(kb), qd, qinv);
+                if (FPR || (J & 15u) == 15u)
+                {
+                    s0 = fp_red(s0, qd, qinv);
+                    s1 = fp_red(s1, qd, qinv);
+                }
+                lo0[e] = d2u(s0);
+                lo1[e] = d2u(s1);
+            }
+            else
+            {
+                mac128r(lo0[e], hi0[e], x, ka);
+                mac128r(lo1[e], hi1[e], x, kb);
+            }
+        }
+    }
+    const uint64_t cr0 = pc->cr0, cr1 = pc->cr1;
+    uint64_t *__restrict__ o0 = a.acc + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN) + obase;
+    uint64_t *__restrict__ o1 = a.acc + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN) + obase;
+    const uint64_t *__restrict__ c0 = a.corr + (((size_t)0 * (a.L + 1) + slot) << LOGN) + obase;
+    const uint64_t *__restrict__ c1 = a.corr + (((size_t)1 * (a.L + 1) + slot) << LOGN) + obase;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+        uint64_t r0, r1;
+        if (FP)
+        {
+            r0 = fp_to_canonical(u2d(lo0[e]), qd, qinv);
+            r1 = fp_to_canonical(u2d(lo1[e]), qd, qinv);
+        }
+        else
+        {
+            r0 = barrett128(lo0[e], hi0[e], q, cr0, cr1);
+            r1 = barrett128(lo1[e], hi1[e], q, cr0, cr1);
+        }
+        o0[(size_t)e << 8] = csub(r0 + c0[(size_t)e << 8], q);
+        o1[(size_t)e << 8] = csub(r1 + c1[(size_t)e << 8], q);
+    }
+}
+
 // ---- "divide by the last modulus and round" with its element-wise halves fused into the NTT ---------
 // (RNSTool::divide_and_round_q_last_ntt_inplace SEAL/util/rns.cpp:830-901; key-switch mod-down
 // SEAL/evaluator.cpp:2913-3018).  `last` [P][N] is the dropped row in coefficient form.

@@ -60,6 +60,8 @@ SYMBOLS = {
     "moai_apply_galois": (C.c_int, [vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_apply_galois_to": (C.c_int, [vp, vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_modraise": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_hoist_correction": (C.c_int, [vp, vp, C.c_uint32, sz, vp, vp]),
+    "moai_apply_galois_hoisted": (C.c_int, [vp, vp, C.POINTER(vp), sz, C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(vp), sz, sz, C.POINTER(C.c_int), vp]),
     "moai_ckks_encode": (C.c_int, [vp, vp, C.c_int, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
     "moai_ckks_encode_masked": (C.c_int, [vp, vp, vp, sz, sz, vp, sz, C.POINTER(C.c_uint32), C.c_double, vp, vp]),
     "moai_total_coeff_modulus_bit_count": (C.c_int, [vp, sz, C.POINTER(C.c_uint32)]),
@@ -279,6 +281,29 @@ class Context:
 
     def apply_galois_to(self, src, dst, L, elt, key, batch, stream=None):
         _check(lib().moai_apply_galois_to(self.h, _ptr(src), _ptr(dst), L, int(elt), _ptr(key), batch, stream))
+
+    def hoist_correction(self, key, elt, L, stream=None):
+        """the per-(key, level) constant of the hoisted rotations: DeviceBuffer [2][L+1][N]"""
+        out = DeviceBuffer(2 * (L + 1) * self.n)
+        _check(lib().moai_hoist_correction(self.h, _ptr(key), int(elt), L, _ptr(out), stream))
+        return out
+
+    def apply_galois_hoisted(self, src, dst, L, elts, keys, corrections, batch, stream=None):
+        """dst[r] = apply_galois(src, elts[r], keys[r]) for every r with one digit decomposition (dst: one buffer
+        [R][batch][2][L][N] or a list of R buffers); returns True when the library had to fall back to separate calls (a
+        zero coefficient in INTT(c1))"""
+        R = len(elts)
+        if isinstance(dst, (list, tuple)):
+            op = (vp * R)(*[_ptr(d) for d in dst])
+        else:
+            words = batch * 2 * L * self.n * 8
+            op = (vp * R)(*[_ptr(dst) + r * words for r in range(R)])
+        e = (C.c_uint32 * R)(*[int(x) for x in elts])
+        kp = (vp * R)(*[_ptr(k) for k in keys])
+        cp = (vp * R)(*[_ptr(k) for k in corrections])
+        fb = C.c_int(0)
+        _check(lib().moai_apply_galois_hoisted(self.h, _ptr(src), op, L, e, kp, cp, R, batch, C.byref(fb), stream))
+        return bool(fb.value)
 
     def modraise(self, src, out, L_out, batch, stream=None):
         _check(lib().moai_modraise(self.h, _ptr(src), _ptr(out), L_out, batch, stream))

@@ -16,6 +16,7 @@
 // level bookkeeping follow the reference (product scale = input scale squared, level unchanged).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <complex>
 #include <map>
 #include <memory>
@@ -267,14 +268,21 @@ namespace moai_fused
             }
             load(src);
             std::vector<std::uint32_t> seq;
-            for (std::size_t k = 0; k < nb; k++)
+            // The baby steps rotate ONE source: when every step has its own key (the bootstrapping key list has them all,
+            // Bootstrapper.cpp:89-184) and the steps sit back to back in `babies`, they are one hoisted call -- one digit
+            // decomposition instead of one per step, same bits (include/moai_hip.h, moai_apply_galois_hoisted).
+            // MOAI_SHIM_HOIST=0 keeps the separate calls.
+            if (!hoisted_babies(src, babies.get(), batch_words, zero_baby, L, B, gal_keys))
             {
-                if (k == zero_baby)
+                for (std::size_t k = 0; k < nb; k++)
                 {
-                    continue;
+                    if (k == zero_baby)
+                    {
+                        continue;
+                    }
+                    std::uint64_t *dst = babies.get() + k * batch_words;
+                    rotate_batch_from(src, dst, baby_steps_[k], L, B, gal_keys, seq);
                 }
-                std::uint64_t *dst = babies.get() + k * batch_words;
-                rotate_batch_from(src, dst, baby_steps_[k], L, B, gal_keys, seq);
             }
             util::DeviceArray acc(batch_words, st), giant(batch_words, st);
             bool first = true;
@@ -322,6 +330,49 @@ namespace moai_fused
             }
             diagonals_.insert(diagonals_.end(), rotated.begin(), rotated.end());
             return static_cast<std::uint32_t>(diagonals_.size() / static_cast<std::size_t>(Nh_) - 1);
+        }
+
+        // all non-zero baby steps in one moai_apply_galois_hoisted call; false when that form does not apply
+        bool hoisted_babies(const std::uint64_t *src, std::uint64_t *babies, std::size_t batch_words, std::size_t zero_baby, std::size_t L,
+                            std::size_t B, const seal::GaloisKeys &keys) const
+        {
+            static const bool enabled = [] {
+                const char *e = std::getenv("MOAI_SHIM_HOIST");
+                return !(e && e[0] == '0');
+            }();
+            const std::size_t nb = baby_steps_.size();
+            if (!enabled || nb < 3 || context_.logn() < 12)
+            {
+                return false;
+            }
+            const std::size_t count = zero_baby < nb ? nb - 1 : nb;
+            std::vector<std::uint32_t> elts(count);
+            std::vector<const std::uint64_t *> kptr(count), cptr(count);
+            std::vector<std::uint32_t> seq;
+            std::vector<std::uint64_t *> optr(count);
+            for (std::size_t k = 0, i = 0; k < nb; k++)
+            {
+                if (k == zero_baby)
+                {
+                    continue;
+                }
+                seq.clear();
+                detail::rotation_sequence(context_, keys, baby_steps_[k], seq);
+                if (seq.size() != 1)
+                {
+                    return false; // a step without its own key takes the NAF path of rotate_internal
+                }
+                elts[i] = seq[0];
+                const std::size_t index = seal::GaloisKeys::get_index(seq[0]);
+                kptr[i] = keys.device_key(index);
+                cptr[i] = keys.hoist_correction(context_, index, seq[0], L);
+                optr[i] = babies + k * batch_words;
+                i++;
+            }
+            int fell_back = 0;
+            seal::util::hip_check(moai_apply_galois_hoisted(context_.device(), src, optr.data(), L, elts.data(), kptr.data(), cptr.data(), count, B,
+                                                            &fell_back, context_.stream()));
+            return true;
         }
 
         // the same from `src` into `dst`: the first key switch reads the source, the rest work in place

@@ -9,8 +9,11 @@
 // (Q K^T): out[i] = rescale(relinearize( sum_j multiply(X[j], rotate(W[j], i * num_batch)) )).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
+#include <functional>
 #include <iostream>
 #include <map>
+#include <memory>
 
 #include "seal/seal.h"
 
@@ -411,35 +414,83 @@ namespace moai_fused
             util::hip_check(moai_memcpy_d2d(dX.get() + j * ct_words, enc_X[j].device_data(), ct_words * 8, st));
             util::hip_check(moai_memcpy_d2d(dW.get() + j * ct_words, enc_W[j].device_data(), ct_words * 8, st));
         }
-        // stack[d] = all columns of W after the first d + 1 key switches of the current sequence
-        std::vector<util::DeviceArray> stack;
-        std::vector<std::uint32_t> current;
-        for (std::size_t oi = 0; oi < rows; oi++)
+        // The rotation sequences form a prefix tree: a node = all columns of W after a prefix of key switches; the rows
+        // whose sequence ends at a node take their products there.  The children of a node rotate the SAME ciphertexts by
+        // different steps: with two or more of them that is one hoisted call (one digit decomposition for all of them,
+        // moai_apply_galois_hoisted; same bits), otherwise one batched key switch.
+        struct Node
         {
-            const std::size_t i = order[oi];
-            const std::vector<std::uint32_t> &want = seq[i];
-            std::size_t common = 0;
-            while (common < current.size() && common < want.size() && current[common] == want[common])
+            std::map<std::uint32_t, std::unique_ptr<Node>> child;
+            std::vector<std::size_t> ends;
+        };
+        Node root;
+        for (std::size_t i = 0; i < rows; i++)
+        {
+            Node *at = &root;
+            for (std::uint32_t e : seq[i])
             {
-                common++;
+                auto &c = at->child[e];
+                if (!c)
+                {
+                    c.reset(new Node());
+                }
+                at = c.get();
             }
-            current.resize(common);
-            while (stack.size() > common)
-            {
-                stack.pop_back();
-            }
-            for (std::size_t d = common; d < want.size(); d++)
-            {
-                const std::uint64_t *parent = d == 0 ? dW.get() : stack[d - 1].get();
-                stack.emplace_back(cols * ct_words, st);
-                const std::uint64_t *key = RotK.device_key(GaloisKeys::get_index(want[d]));
-                util::hip_check(moai_apply_galois_to(dev, parent, stack.back().get(), L, want[d], key, cols, st));
-                current.push_back(want[d]);
-            }
-            const std::uint64_t *w = want.empty() ? dW.get() : stack.back().get();
-            util::hip_check(moai_ct_dot(dev, dX.get(), w, d3.get() + i * 3 * L * n, cols, L, st));
+            at->ends.push_back(i);
         }
-        stack.clear();
+        (void)order;
+        static const bool hoist = [] {
+            const char *e = std::getenv("MOAI_SHIM_HOIST");
+            return !(e && e[0] == '0');
+        }();
+        std::function<void(const Node &, const std::uint64_t *)> walk = [&](const Node &node, const std::uint64_t *buf) {
+            for (std::size_t i : node.ends)
+            {
+                util::hip_check(moai_ct_dot(dev, dX.get(), buf, d3.get() + i * 3 * L * n, cols, L, st));
+            }
+            if (node.child.empty())
+            {
+                return;
+            }
+            std::vector<util::DeviceArray> kids;
+            kids.reserve(node.child.size());
+            std::vector<std::uint32_t> elts;
+            std::vector<const std::uint64_t *> kptr, cptr;
+            std::vector<std::uint64_t *> optr;
+            for (auto &kv : node.child)
+            {
+                kids.emplace_back(cols * ct_words, st);
+                elts.push_back(kv.first);
+                const std::size_t index = GaloisKeys::get_index(kv.first);
+                kptr.push_back(RotK.device_key(index));
+                optr.push_back(kids.back().get());
+            }
+            if (hoist && elts.size() >= 2 && seal_context.logn() >= 12)
+            {
+                for (std::uint32_t e : elts)
+                {
+                    cptr.push_back(RotK.hoist_correction(seal_context, GaloisKeys::get_index(e), e, L));
+                }
+                int fell_back = 0;
+                util::hip_check(moai_apply_galois_hoisted(dev, buf, optr.data(), L, elts.data(), kptr.data(), cptr.data(), elts.size(), cols,
+                                                          &fell_back, st));
+            }
+            else
+            {
+                for (std::size_t c = 0; c < elts.size(); c++)
+                {
+                    util::hip_check(moai_apply_galois_to(dev, buf, optr[c], L, elts[c], kptr[c], cols, st));
+                }
+            }
+            std::size_t c = 0;
+            for (auto &kv : node.child)
+            {
+                walk(*kv.second, kids[c].get());
+                kids[c] = util::DeviceArray(); // release as soon as the subtree is done
+                c++;
+            }
+        };
+        walk(root, dW.get());
         util::DeviceArray d2(rows * ct_words, st), dres(rows * 2 * (L - 1) * n, st);
         util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0), d2.get(), L, rows, st));
         util::hip_check(moai_rescale(dev, d2.get(), dres.get(), 2, L, rows, st));

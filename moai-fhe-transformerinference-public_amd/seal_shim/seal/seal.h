@@ -1172,11 +1172,20 @@ namespace seal
         {
             return index < keys_.size() && keys_[index] ? keys_[index]->get() : nullptr;
         }
+        // the per-(key, level) constant of hoisted rotations (moai_hoist_correction), computed on first use and kept for
+        // the lifetime of the key object; [2][L+1][N] on the device
+        const std::uint64_t *hoist_correction(const SEALContext &context, std::size_t index, std::uint32_t galois_elt, std::size_t L) const;
 
     protected:
         friend class KeyGenerator;
         parms_id_type parms_id_ = parms_id_zero;
         std::vector<std::shared_ptr<util::DeviceArray>> keys_;
+        struct HoistCache
+        {
+            std::mutex mu;
+            std::map<std::pair<std::size_t, std::size_t>, std::shared_ptr<util::DeviceArray>> blocks;
+        };
+        mutable std::shared_ptr<HoistCache> hoist_ = std::make_shared<HoistCache>();
     };
 
     class RelinKeys : public KSwitchKeys
@@ -1212,6 +1221,24 @@ namespace seal
             return device_key(get_index(galois_elt)) != nullptr;
         }
     };
+    inline const std::uint64_t *KSwitchKeys::hoist_correction(const SEALContext &context, std::size_t index, std::uint32_t galois_elt,
+                                                              std::size_t L) const
+    {
+        const std::uint64_t *key = device_key(index);
+        if (!key)
+        {
+            throw std::invalid_argument("Galois key not present");
+        }
+        std::lock_guard<std::mutex> g(hoist_->mu);
+        auto &slot = hoist_->blocks[std::make_pair(index, L)];
+        if (!slot)
+        {
+            auto block = std::make_shared<util::DeviceArray>(2 * (L + 1) * context.n(), context.stream());
+            util::hip_check(moai_hoist_correction(context.device(), key, galois_elt, L, block->get(), context.stream()));
+            slot = block;
+        }
+        return slot->get();
+    }
 } // namespace seal
 
 #include "seal/moai_combiner.h"

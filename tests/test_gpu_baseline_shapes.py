@@ -217,3 +217,30 @@ def test_config3_ct_pt_columns(moai, env16):
     for c in check:
         assert (got[c] == want[c][0]).all(), c
         assert (res[c] == want[c][1]).all(), c
+
+
+def test_hoisted_baby_step_rotations_at_moai_top_level(moai, env16):
+    """the baby steps of a bootstrapping transform as ONE hoisted call at N = 2^16, l = 35, batch 2: three rotations of the
+    same ciphertexts against the oracle's separate rotate_vector calls, under both arithmetics"""
+    e = env16
+    L, B = 35, 2
+    rng = np.random.default_rng(350)
+    ct = O.uniform_rns(rng, e.primes[:L], (B, 2), N)
+    steps = [1, 1024, -4]
+    elts = [e.ctx.galois_elt_from_step(s) for s in steps]
+    keys = [e.key(30 + i) for i in range(len(steps))]
+    want = pool_map(lambda rb: e.octx.apply_galois(ct[rb[1]], L, elts[rb[0]], keys[rb[0]][0]).reshape(2, L, N),
+                    [(r, b) for r in range(len(steps)) for b in range(B)])
+    corrs = [e.ctx.hoist_correction(keys[r][1], elts[r], L) for r in range(len(steps))]
+    try:
+        for arith in ("fp64", "int64"):
+            set_arith(moai, arith)
+            dout = moai.DeviceBuffer(len(steps) * B * 2 * L * N)
+            assert not e.ctx.apply_galois_hoisted(up(moai, ct), dout, L, elts, [kk[1] for kk in keys], corrs, B)
+            got = dout.to_numpy((len(steps), B, 2, L, N))
+            for r in range(len(steps)):
+                for b in range(B):
+                    assert (got[r, b] == want[r * B + b]).all(), (arith, r, b)
+            dout.free()
+    finally:
+        reset_tuning(moai)

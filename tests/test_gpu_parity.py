@@ -691,3 +691,41 @@ def test_fp64_modes_at_their_size_limits(moai):
     finally:
         moai.hip.set_tuning("MOAI_KS_FP_MIN_ROWS", 16)
         moai.hip.set_tuning("MOAI_MD_FP_MIN_ROWS", 256)
+
+
+@pytest.mark.parametrize("logn,bits,L,B", [(12, [51, 46, 46, 51, 58], 4, 3), (12, [60, 46, 51, 61], 3, 2), (13, [46, 46, 51, 58], 2, 1)])
+def test_hoisted_rotations_equal_separate_rotations(moai, logn, bits, L, B, ks_arith):
+    """moai_apply_galois_hoisted: R rotations of one ciphertext with ONE digit decomposition (the baby steps of MOAI's
+    bootstrapping transforms) against the oracle's apply_galois per rotation (SEAL/evaluator.cpp:2563-2665 over
+    :2724-3020), bit for bit; steps with positive and negative sign patterns and the conjugation; a ciphertext with a
+    zero coefficient in INTT(c1) must take the fallback and still match."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k = len(primes)
+    rng = np.random.default_rng(logn * 10 + L)
+    steps = [1, 3, -2, 64, 0]  # 0 = conjugation (galois element 2N - 1)
+    elts = [ctx.galois_elt_from_step(s) if s else 2 * n - 1 for s in steps]
+    keys = [O.uniform_rns(rng, primes, (k - 1, 2), n) for _ in steps]
+    dkeys = [up(moai, kk) for kk in keys]
+    corrs = [ctx.hoist_correction(dk, e, L) for dk, e in zip(dkeys, elts)]
+    ct = O.uniform_rns(rng, primes[:L], (B, 2), n)
+    dct = up(moai, ct)
+    dout = moai.DeviceBuffer(len(steps) * B * 2 * L * n)
+    fell_back = ctx.apply_galois_hoisted(dct, dout, L, elts, dkeys, corrs, B)
+    assert not fell_back
+    got = dout.to_numpy((len(steps), B, 2, L, n))
+    for r, (e, kk) in enumerate(zip(elts, keys)):
+        for b in range(B):
+            assert (got[r, b] == octx.apply_galois(ct[b], L, e, kk).reshape(2, L, n)).all(), (r, b)
+    assert (dct.to_numpy(ct.shape) == ct).all()  # the input is left alone
+    # a transparent-looking input: c1 = NTT(polynomial with zero coefficients) -> the identity does not hold -> fallback
+    ct0 = ct.copy()
+    sparse = np.zeros((1, L, n), dtype=np.uint64)
+    sparse[0, :, 1] = 5
+    ct0[0, 1] = octx.ntt(sparse, L)[0]
+    dct0 = up(moai, ct0)
+    assert ctx.apply_galois_hoisted(dct0, dout, L, elts, dkeys, corrs, B)
+    got = dout.to_numpy((len(steps), B, 2, L, n))
+    for r, (e, kk) in enumerate(zip(elts, keys)):
+        assert (got[r, 0] == octx.apply_galois(ct0[0], L, e, kk).reshape(2, L, n)).all(), r

@@ -4,6 +4,8 @@
 // executed on the device through moai_ntt_forward / moai_ntt_inverse.
 #pragma once
 #include <cerrno>
+#include <exception>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -835,16 +837,44 @@ namespace seal
             }
             util::hip_check(moai_mul_scalar_rows(context_.device(), new_key_ntt, factor.data(), scaled.get(), 1, k_,
                                                  context_.stream()));
-            // addend [k][N]: zero except row J = (p mod q_J) * new_key[J]
-            util::DeviceArray sparse(k_ * n_, context_.stream());
-            util::hip_check(moai_memset_zero(sparse.get(), k_ * n_ * 8, context_.stream()));
-            for (std::size_t J = 0; J < digits; J++)
+            // The digits are independent encryptions of zero: host threads draw their randomness side by side (a key at
+            // MOAI's size is 35 x 2 x 36 x 65536 samples) and enqueue on the context's one stream, where each digit's own
+            // operations keep their order.  Every thread adds through its own addend [k][N], zero except row J =
+            // (p mod q_J) * new_key[J].
+            std::exception_ptr failure;
+#pragma omp parallel
             {
-                std::uint64_t *ct = key->get() + J * 2 * k_ * n_;
-                encrypt_zero_symmetric(ct);
-                util::hip_check(moai_memcpy_d2d(sparse.get() + J * n_, scaled.get() + J * n_, n_ * 8, context_.stream()));
-                util::hip_check(moai_add(context_.device(), ct, sparse.get(), ct, 1, k_, context_.stream()));
-                util::hip_check(moai_memset_zero(sparse.get() + J * n_, n_ * 8, context_.stream()));
+                std::unique_ptr<util::DeviceArray> sparse;
+#pragma omp for schedule(dynamic)
+                for (std::size_t J = 0; J < digits; J++)
+                {
+                    try
+                    {
+                        if (!sparse)
+                        {
+                            sparse.reset(new util::DeviceArray(k_ * n_, context_.stream()));
+                            util::hip_check(moai_memset_zero(sparse->get(), k_ * n_ * 8, context_.stream()));
+                        }
+                        std::uint64_t *ct = key->get() + J * 2 * k_ * n_;
+                        encrypt_zero_symmetric(ct);
+                        util::hip_check(moai_memcpy_d2d(sparse->get() + J * n_, scaled.get() + J * n_, n_ * 8, context_.stream()));
+                        util::hip_check(moai_add(context_.device(), ct, sparse->get(), ct, 1, k_, context_.stream()));
+                        util::hip_check(moai_memset_zero(sparse->get() + J * n_, n_ * 8, context_.stream()));
+                    }
+                    catch (...)
+                    {
+#pragma omp critical(moai_keygen_failure)
+                        failure = std::current_exception();
+                    }
+                }
+                if (sparse)
+                {
+                    context_.sync(); // before this thread's addend is released
+                }
+            }
+            if (failure)
+            {
+                std::rethrow_exception(failure);
             }
             context_.sync();
             return key;

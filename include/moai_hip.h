@@ -290,6 +290,8 @@ size_t moai_op_trace_dump(char *buf, size_t cap);
  * HIP events on the caller's stream is not provided here; callers time with their own events
  * around the calls (bench.py does).  moai_device_info fills name (<= 255 chars) and CU count. */
 int moai_device_info(int device, char *name, size_t name_cap, int *compute_units, size_t *hbm_bytes);
+/* free and total device memory of the current device (hipMemGetInfo) */
+int moai_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* hipEvent helpers so that pure-C / ctypes callers can time the stream the kernels run on */
 int moai_event_create(void **event);
 int moai_event_destroy(void *event);

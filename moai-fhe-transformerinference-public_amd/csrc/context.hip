@@ -708,6 +708,21 @@ extern "C" int moai_device_info(int device, char *name, size_t cap, int *cus, si
     return MOAI_OK;
 }
 
+extern "C" int moai_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    MOAI_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes)
+    {
+        *free_bytes = f;
+    }
+    if (total_bytes)
+    {
+        *total_bytes = t;
+    }
+    return MOAI_OK;
+}
+
 extern "C" int moai_event_create(void **ev)
 {
     hipEvent_t e;

@@ -67,6 +67,7 @@ SYMBOLS = {
     "moai_total_coeff_modulus_bit_count": (C.c_int, [vp, sz, C.POINTER(C.c_uint32)]),
     "moai_ckks_tables": (C.c_int, [vp, vp, vp]),
     "moai_set_tuning": (C.c_int, [C.c_char_p, C.c_long]),
+    "moai_mem_info": (C.c_int, [C.POINTER(sz), C.POINTER(sz)]),
     "moai_op_trace": (C.c_int, [C.c_int]),
     "moai_op_trace_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "moai_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),

@@ -284,8 +284,16 @@ namespace seal
                 int rc = moai_malloc(&p, bytes);
                 if (rc != MOAI_OK)
                 {
-                    trim(); // give cached blocks back and retry once
-                    hip_check(moai_malloc(&p, bytes));
+                    // Out of device memory: ONE thread gives the cached blocks back (every hipFree waits for the device, so
+                    // this takes a while); the others wait here and retry once it is done -- a thread that retried while the
+                    // blocks were still being freed would fail for good (MOAI's OpenMP loops allocate from 16+ threads).
+                    std::lock_guard<std::mutex> g(oom_mu_);
+                    rc = moai_malloc(&p, bytes);
+                    if (rc != MOAI_OK)
+                    {
+                        trim();
+                        hip_check(moai_malloc(&p, bytes));
+                    }
                 }
                 return p;
             }
@@ -326,9 +334,9 @@ namespace seal
             DevicePool()
             {
                 const char *e = std::getenv("MOAI_POOL_CACHE_MB");
-                cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(131072)) << 20;
+                cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(114688)) << 20; // 112 GiB: freed blocks are worth keeping (every hipFree waits for the device); an allocation that fails trims the cache
             }
-            std::mutex mu_;
+            std::mutex mu_, oom_mu_;
             std::map<std::pair<void *, std::size_t>, std::vector<void *>> free_;
             std::size_t cached_ = 0, cap_ = 0;
         };

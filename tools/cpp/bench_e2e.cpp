@@ -36,6 +36,13 @@ static double now_s()
     return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static void report_memory(const char *where)
+{
+    size_t f = 0, t = 0;
+    moai_mem_info(&f, &t);
+    printf("  [device memory at %s: %.1f GiB free of %.1f]\n", where, f / 1073741824.0, t / 1073741824.0);
+}
+
 static string census_json()
 {
     size_t need = moai_op_trace_dump(nullptr, 0);
@@ -111,6 +118,7 @@ int main(int argc, char **argv)
     bootstrapper.generate_LT_coefficient_3();
     context.sync();
     const double setup_s = now_s() - t_start;
+    report_memory("start of the measurements");
     printf("setup (context, %zu + %d rotation keys, relinearization key, bootstrapping constants): %.1f s\n", gal_steps_vector.size(),
            with_head ? 31 : 0, setup_s);
 
@@ -166,6 +174,7 @@ int main(int argc, char **argv)
     printf("bootstrap_3: %.2f ms per ciphertext in one pack of %d; %.2f ms through %d single-ciphertext calls from %d threads; "
            "chain index 0 -> %zu, max |error| %.2e\n",
            boot_packed_ms, pack, boot_calls_ms, pack, threads, boot_index, boot_err);
+    report_memory("end of the bootstrapping part");
     low.clear();
     outs.clear();
     packed = Ciphertext();
@@ -206,6 +215,7 @@ int main(int argc, char **argv)
             while (context.get_context_data(enc_X[i].parms_id())->chain_index() > 15) evaluator.mod_switch_to_next_inplace(enc_X[i]);
         context.sync();
         printf("768 input ciphertexts encrypted and switched to chain index 15: %.1f s\n", now_s() - t0);
+        report_memory("start of the attention head");
         moai_op_trace(1);
         t0 = now_s();
         vector<Ciphertext> out = single_att_block(enc_X, WQ, WK, WV, bQ, bK, bV, b_vec, input_num, context, relin_keys, gal_keys, bootstrapper,

@@ -292,6 +292,13 @@ namespace seal
                     if (rc != MOAI_OK)
                     {
                         trim();
+                        {
+                            // the cache outgrew what this device has to spare: keep less from now on, so that the next
+                            // shortage is not another full trim (thousands of hipFree calls, each waiting for the device)
+                            std::lock_guard<std::mutex> g2(mu_);
+                            const std::size_t floor_bytes = std::size_t(8) << 30;
+                            cap_ = cap_ / 2 > floor_bytes ? cap_ / 2 : floor_bytes;
+                        }
                         hip_check(moai_malloc(&p, bytes));
                     }
                 }

@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -264,7 +265,7 @@ namespace seal
                     {
                         if (!it->second.empty())
                         {
-                            void *p = it->second.back();
+                            void *p = it->second.back().ptr; // the most recently released: the old ones age towards a trim
                             it->second.pop_back();
                             cached_ -= it->first.second;
                             if (granted)
@@ -284,22 +285,25 @@ namespace seal
                 int rc = moai_malloc(&p, bytes);
                 if (rc != MOAI_OK)
                 {
-                    // Out of device memory: ONE thread gives the cached blocks back (every hipFree waits for the device, so
-                    // this takes a while); the others wait here and retry once it is done -- a thread that retried while the
-                    // blocks were still being freed would fail for good (MOAI's OpenMP loops allocate from 16+ threads).
+                    // Out of device memory: ONE thread gives cached blocks back -- the least recently released first (the
+                    // sizes of a stage that is over, not the ones the running stage keeps reusing), a quarter of the cache
+                    // at a time, because every hipFree waits for the device; the other threads wait here and retry once
+                    // it is done (a thread that retried while the blocks were still being freed would fail for good:
+                    // MOAI's OpenMP loops allocate from 16+ threads).
                     std::lock_guard<std::mutex> g(oom_mu_);
                     rc = moai_malloc(&p, bytes);
-                    if (rc != MOAI_OK)
+                    while (rc != MOAI_OK)
                     {
-                        trim();
+                        std::size_t want;
                         {
-                            // the cache outgrew what this device has to spare: keep less from now on, so that the next
-                            // shortage is not another full trim (thousands of hipFree calls, each waiting for the device)
                             std::lock_guard<std::mutex> g2(mu_);
-                            const std::size_t floor_bytes = std::size_t(8) << 30;
-                            cap_ = cap_ / 2 > floor_bytes ? cap_ / 2 : floor_bytes;
+                            want = std::max<std::size_t>({ 4 * bytes, cached_ / 4, std::size_t(8) << 30 });
                         }
-                        hip_check(moai_malloc(&p, bytes));
+                        if (trim(want) == 0)
+                        {
+                            hip_check(rc); // nothing left to give back
+                        }
+                        rc = moai_malloc(&p, bytes);
                     }
                 }
                 return p;
@@ -310,28 +314,69 @@ namespace seal
                     std::lock_guard<std::mutex> g(mu_);
                     if (cached_ + bytes <= cap_)
                     {
-                        free_[{ stream, bytes }].push_back(p);
+                        free_[{ stream, bytes }].push_back({ p, ++clock_ });
                         cached_ += bytes;
                         return;
                     }
                 }
                 moai_free(p);
             }
-            void trim()
+            // gives cached blocks back to the device, least recently released first, until `at_least` bytes are returned
+            // (everything by default); returns the bytes freed
+            std::size_t trim(std::size_t at_least = ~std::size_t(0))
             {
-                std::map<std::pair<void *, std::size_t>, std::vector<void *>> old;
+                std::vector<void *> victims;
+                std::size_t freed = 0;
                 {
                     std::lock_guard<std::mutex> g(mu_);
-                    old.swap(free_);
-                    cached_ = 0;
-                }
-                for (auto &kv : old)
-                {
-                    for (void *p : kv.second)
+                    struct Age
                     {
-                        moai_free(p);
+                        std::uint64_t tick;
+                        std::size_t bytes;
+                    };
+                    std::vector<Age> ages;
+                    for (auto &kv : free_)
+                    {
+                        for (auto &blk : kv.second)
+                        {
+                            ages.push_back({ blk.tick, kv.first.second });
+                        }
                     }
+                    std::sort(ages.begin(), ages.end(), [](const Age &a, const Age &b) { return a.tick < b.tick; });
+                    std::uint64_t newest_victim = 0;
+                    for (auto &a : ages)
+                    {
+                        if (freed >= at_least)
+                        {
+                            break;
+                        }
+                        freed += a.bytes;
+                        newest_victim = a.tick;
+                    }
+                    for (auto it = free_.begin(); it != free_.end();)
+                    {
+                        auto &list = it->second; // ticks ascend within a list: the victims are a prefix
+                        std::size_t k = 0;
+                        while (k < list.size() && list[k].tick <= newest_victim && freed)
+                        {
+                            victims.push_back(list[k].ptr);
+                            k++;
+                        }
+                        list.erase(list.begin(), list.begin() + static_cast<std::ptrdiff_t>(k));
+                        it = list.empty() ? free_.erase(it) : std::next(it);
+                    }
+                    cached_ -= freed;
                 }
+                for (void *p : victims)
+                {
+                    moai_free(p);
+                }
+                return freed;
+            }
+            std::size_t cached_bytes()
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                return cached_;
             }
             // cached blocks are deliberately not returned at static destruction: the HIP runtime may already be
             // gone by then, and the process is exiting anyway
@@ -344,8 +389,14 @@ namespace seal
                 cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(114688)) << 20; // 112 GiB: freed blocks are worth keeping (every hipFree waits for the device); an allocation that fails trims the cache
             }
             std::mutex mu_, oom_mu_;
-            std::map<std::pair<void *, std::size_t>, std::vector<void *>> free_;
+            struct Block
+            {
+                void *ptr;
+                std::uint64_t tick; // value of clock_ when it was released
+            };
+            std::map<std::pair<void *, std::size_t>, std::vector<Block>> free_;
             std::size_t cached_ = 0, cap_ = 0;
+            std::uint64_t clock_ = 0;
         };
 
         // RAII device buffer of uint64 words

@@ -505,10 +505,41 @@ static void packed_random_program()
     }
 }
 
+// util::DevicePool: same-stream reuse, and the order in which a shortage gives blocks back (least recently released first)
+static void device_pool()
+{
+    auto &pool = seal::util::DevicePool::instance();
+    pool.trim();
+    CHECK(pool.cached_bytes() == 0);
+    const size_t MB = size_t(1) << 20;
+    size_t ga = 0, gb = 0, gc = 0;
+    void *a = pool.acquire(MB, nullptr, &ga), *b = pool.acquire(2 * MB, nullptr, &gb), *c = pool.acquire(MB, nullptr, &gc);
+    CHECK(ga == MB && gb == 2 * MB && gc == MB);
+    pool.release(a, ga, nullptr);
+    pool.release(b, gb, nullptr);
+    pool.release(c, gc, nullptr);
+    CHECK(pool.cached_bytes() == 4 * MB);
+    CHECK(pool.trim(MB) == MB); // a, the oldest, goes
+    CHECK(pool.cached_bytes() == 3 * MB);
+    size_t g1 = 0;
+    void *c2 = pool.acquire(MB, nullptr, &g1);
+    CHECK(c2 == c && g1 == MB); // c is still cached and is what a request of its size gets
+    CHECK(pool.cached_bytes() == 2 * MB);
+    size_t g2 = 0;
+    void *b2 = pool.acquire(3 * MB / 2, nullptr, &g2); // best fit within 1.5 x the request
+    CHECK(b2 == b && g2 == 2 * MB);
+    CHECK(pool.cached_bytes() == 0);
+    pool.release(c2, g1, nullptr);
+    pool.release(b2, g2, nullptr);
+    CHECK(pool.trim(MB + 1) == 3 * MB); // whole blocks, oldest first, until at least that much is back
+    CHECK(pool.trim() == 0);
+}
+
 int main()
 {
     try
     {
+        device_pool();
         config1();
         evaluator_ops();
         concurrent_callers();

@@ -63,11 +63,29 @@ static string census_json()
     return out.str();
 }
 
+// host threads this process may really use: OpenMP's count capped by the cgroup CPU quota (a GPU box shows every core of
+// the host but grants a share of them) and by 32 -- the host only issues device work
+static int usable_threads()
+{
+    int n = omp_get_max_threads();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+    {
+        char quota[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") && period > 0)
+        {
+            n = std::min<long>(n, std::max<long>(1, atol(quota) / period));
+        }
+        fclose(f);
+    }
+    return std::min(n, 32);
+}
+
 int main(int argc, char **argv)
 {
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const int pack = argc > 1 ? atoi(argv[1]) : 48;
-    const int threads = argc > 2 ? atoi(argv[2]) : omp_get_max_threads();
+    const int threads = argc > 2 ? atoi(argv[2]) : usable_threads();
     const bool with_head = !(argc > 3 && !strcmp(argv[3], "--no-head"));
     omp_set_num_threads(threads);
     const double t_start = now_s();

@@ -136,6 +136,12 @@ int moai_ct_multiply(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64
                      void *stream);
 /* Evaluator::ckks_square SEAL/evaluator.cpp:1223-1282: (x0^2, 2 x0 x1, x1^2) */
 int moai_ct_square(moai_ctx *ctx, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream);
+/* Evaluator::multiply for operands of any size, SEAL/evaluator.cpp:862-900 (the dest_size != 3 branch of ckks_multiply):
+ * out[b][k] = sum over i + j = k of x[b][i] (*) y[b][j], k < size_x + size_y - 1.
+ * x: [batch][size_x][L][N]; y: [batch][size_y][L][N]; out: [batch][size_x + size_y - 1][L][N], not an operand.
+ * Sizes 2..16, product at most 16 polynomials (SEAL_CIPHERTEXT_SIZE_MAX). For 2 x 2 moai_ct_multiply is the same result. */
+int moai_ct_multiply_general(moai_ctx *ctx, const uint64_t *x, size_t size_x, const uint64_t *y, size_t size_y,
+                             uint64_t *out, size_t L, size_t batch, void *stream);
 /* sum over j < count of ckks_multiply(x[j], y[j]) (evaluator.cpp:805-860) accumulated with add_inplace
  * (:155-240): the inner loop of include/source/matrix_mul/Ct_ct_matrix_mul.hpp:33-42 and :117-131 in one pass.
  * x, y: [count][2][L][N]; out: [3][L][N].  Same canonical residues as the reference's multiply-reduce-add

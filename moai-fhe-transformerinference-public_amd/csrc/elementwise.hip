@@ -171,6 +171,47 @@ __global__ __launch_bounds__(256) void ct_mul_kernel(CtMulArgs g)
     }
 }
 
+struct CtMulGeneralArgs
+{
+    const uint64_t *x; // [batch][sx][L][N]
+    const uint64_t *y; // [batch][sy][L][N]
+    uint64_t *out;     // [batch][sx + sy - 1][L][N]
+    const PrimeConst *pc;
+    uint32_t L, n2, sx, sy;
+};
+
+// Evaluator::ckks_multiply, the branch for dest_size != 3 (SEAL/evaluator.cpp:862-900): output polynomial k is the sum over
+// i + j = k of x[i] (*) y[j], every product reduced and every partial sum reduced (the order of the terms cannot matter: each
+// step is exact mod q).  blockIdx.y = (b * dest + k) * L + prime.
+__global__ __launch_bounds__(256) void ct_mul_general_kernel(CtMulGeneralArgs g)
+{
+    const uint32_t dest = g.sx + g.sy - 1;
+    const uint32_t prime = blockIdx.y % g.L;
+    const uint32_t k = (blockIdx.y / g.L) % dest;
+    const uint32_t b = blockIdx.y / (g.L * dest);
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const size_t rs = g.n2;
+    const uint32_t x_last = k < g.sx - 1 ? k : g.sx - 1;
+    const uint32_t y_first = k < g.sy - 1 ? k : g.sy - 1;
+    const uint32_t x_first = k - y_first;
+    const ulonglong2 *x = reinterpret_cast<const ulonglong2 *>(g.x) + ((size_t)(b * g.sx + x_first) * g.L + prime) * rs;
+    const ulonglong2 *y = reinterpret_cast<const ulonglong2 *>(g.y) + ((size_t)(b * g.sy + y_first) * g.L + prime) * rs;
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.out) + ((size_t)(b * dest + k) * g.L + prime) * rs;
+    const size_t poly = (size_t)g.L * rs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        ulonglong2 acc = make_ulonglong2(0, 0);
+        for (uint32_t s = 0; s <= x_last - x_first; s++)
+        {
+            const ulonglong2 a = x[s * poly + i], c = (y - s * poly)[i];
+            acc.x = csub(acc.x + mulmod_barrett(a.x, c.x, q, cr0, cr1), q);
+            acc.y = csub(acc.y + mulmod_barrett(a.y, c.y, q, cr0, cr1), q);
+        }
+        o[i] = acc;
+    }
+}
+
 // out row (p, i<Lout) = in row (p, i): blockIdx.y = p * Lout + i
 __global__ __launch_bounds__(256) void drop_rows_kernel(const uint64_t *in, uint64_t *out, uint32_t Lin, uint32_t Lout,
                                                         uint32_t n2)
@@ -673,6 +714,48 @@ extern "C" int moai_ct_square(moai_ctx *c, const uint64_t *x, uint64_t *out, siz
 {
     trace_op("ct_square", L, batch);
     return ct_mul(c, x, x, out, L, batch, stream, true);
+}
+
+extern "C" int moai_ct_multiply_general(moai_ctx *c, const uint64_t *x, size_t size_x, const uint64_t *y, size_t size_y,
+                                        uint64_t *out, size_t L, size_t batch, void *stream)
+{
+    trace_op("ct_multiply_general", L, batch);
+    if (size_x < 2 || size_y < 2 || size_x > 16 || size_y > 16 || size_x + size_y - 1 > 16)
+    {
+        // SEAL_CIPHERTEXT_SIZE_MIN / _MAX (SEAL/util/defines.h) bound both operands and the product
+        return set_error(MOAI_EINVAL, "ciphertext sizes must be 2..16 and their product at most 16 polynomials");
+    }
+    const size_t dest = size_x + size_y - 1;
+    int rc = check_rows(c, batch * dest, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!x || !y || !out)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    if (out == x || out == y)
+    {
+        return set_error(MOAI_EINVAL, "out must not alias an input");
+    }
+    CtMulGeneralArgs g;
+    g.x = x;
+    g.y = y;
+    g.out = out;
+    g.pc = c->pc;
+    g.L = (uint32_t)L;
+    g.n2 = (uint32_t)(c->n >> 1);
+    g.sx = (uint32_t)size_x;
+    g.sy = (uint32_t)size_y;
+    MOAI_CHECK_GRID_ROWS(batch * dest * L);
+    hipLaunchKernelGGL(ct_mul_general_kernel, row_grid(c, batch * dest * L), dim3(256), 0, (hipStream_t)stream, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
 }
 
 extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t count, size_t L,

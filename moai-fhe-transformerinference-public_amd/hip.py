@@ -47,6 +47,7 @@ SYMBOLS = {
     "moai_add_scalar_rows": (C.c_int, [vp, vp, u64p, vp, sz, sz, vp]),
     "moai_ct_multiply": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_square": (C.c_int, [vp, vp, vp, sz, sz, vp]),
+    "moai_ct_multiply_general": (C.c_int, [vp, vp, sz, vp, sz, vp, sz, sz, vp]),
     "moai_ct_dot": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_pt_dot": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, vp]),
     "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
@@ -237,6 +238,9 @@ class Context:
 
     def ct_multiply(self, x, y, out, L, batch, stream=None):
         _check(lib().moai_ct_multiply(self.h, _ptr(x), _ptr(y), _ptr(out), L, batch, stream))
+
+    def ct_multiply_general(self, x, size_x, y, size_y, out, L, batch, stream=None):
+        _check(lib().moai_ct_multiply_general(self.h, _ptr(x), size_x, _ptr(y), size_y, _ptr(out), L, batch, stream))
 
     def ct_square(self, x, out, L, batch, stream=None):
         _check(lib().moai_ct_square(self.h, _ptr(x), _ptr(out), L, batch, stream))

@@ -15,6 +15,7 @@
 // Modular sums are associative, so the order of the additions does not matter for the residues; scale and
 // level bookkeeping follow the reference (product scale = input scale squared, level unchanged).
 #pragma once
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <complex>
@@ -341,6 +342,20 @@ namespace moai_fused
                 return !(e && e[0] == '0');
             }();
             const std::size_t nb = baby_steps_.size();
+            if (std::getenv("MOAI_SHIM_HOIST_DEBUG"))
+            {
+                std::fprintf(stderr, "[hoist] L=%zu: baby steps", L);
+                for (int s : baby_steps_)
+                {
+                    std::fprintf(stderr, " %d", s);
+                }
+                std::fprintf(stderr, "; giant steps");
+                for (auto &g : giants_)
+                {
+                    std::fprintf(stderr, " %d", g.step);
+                }
+                std::fprintf(stderr, "\n");
+            }
             if (!enabled || nb < 3 || context_.logn() < 12)
             {
                 return false;
@@ -360,6 +375,11 @@ namespace moai_fused
                 detail::rotation_sequence(context_, keys, baby_steps_[k], seq);
                 if (seq.size() != 1)
                 {
+                    if (std::getenv("MOAI_SHIM_HOIST_DEBUG"))
+                    {
+                        std::fprintf(stderr, "[hoist] L=%zu: %zu baby steps, step %d takes %zu key switches: separate calls\n", L, nb,
+                                     baby_steps_[k], seq.size());
+                    }
                     return false; // a step without its own key takes the NAF path of rotate_internal
                 }
                 elts[i] = seq[0];

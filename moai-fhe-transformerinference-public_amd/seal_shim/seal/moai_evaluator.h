@@ -134,9 +134,10 @@ namespace seal
             {
                 throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
             }
-            if (encrypted1.size() != 2 || encrypted2.size() != 2)
+            const std::size_t size1 = encrypted1.size(), size2 = encrypted2.size();
+            if (size1 + size2 - 1 > 16) // product_fits_in: SEAL_CIPHERTEXT_SIZE_MAX (SEAL/evaluator.cpp:790-793)
             {
-                throw std::logic_error("only size-2 by size-2 products are provided on the device");
+                throw std::logic_error("invalid parameters");
             }
             auto cd = context_.get_context_data(encrypted1.parms_id());
             double new_scale = encrypted1.scale() * encrypted2.scale();
@@ -149,8 +150,14 @@ namespace seal
                 throw std::invalid_argument("encrypted1 and encrypted2 pack different numbers of ciphertexts");
             }
             const std::size_t L = encrypted1.coeff_modulus_size(), B = encrypted1.batch();
-            out.resize_batch(context_, encrypted1.parms_id(), 3, B);
-            if (&encrypted1 == &encrypted2 || encrypted1.device_data() == encrypted2.device_data())
+            out.resize_batch(context_, encrypted1.parms_id(), size1 + size2 - 1, B);
+            if (size1 != 2 || size2 != 2)
+            {
+                // the dest_size != 3 branch (:862-900); ckks_square of a larger ciphertext is this product with itself (:1237-1241)
+                hip(moai_ct_multiply_general(dev(), encrypted1.device_data(), size1, encrypted2.device_data(), size2,
+                                             out.device_data(), L, B, st()));
+            }
+            else if (&encrypted1 == &encrypted2 || encrypted1.device_data() == encrypted2.device_data())
             {
                 hip(moai_ct_square(dev(), encrypted1.device_data(), out.device_data(), L, B, st()));
             }
@@ -204,11 +211,7 @@ namespace seal
             {
                 return;
             }
-            if (encrypted.size() != 3)
-            {
-                throw std::logic_error("only size-3 ciphertexts can be relinearized on the device");
-            }
-            if (relin_keys.size() < 1)
+            if (relin_keys.size() < encrypted.size() - 2)
             {
                 throw std::invalid_argument("not enough relinearization keys");
             }
@@ -217,6 +220,35 @@ namespace seal
                 throw std::invalid_argument("CKKS encrypted must be in NTT form");
             }
             const std::size_t L = encrypted.coeff_modulus_size();
+            if (encrypted.size() > 3)
+            {
+                // :1385-1393: the last polynomial is switched with relin_keys[get_index(size - 1)] into (c0, c1) and dropped,
+                // until two are left.  (KeyGenerator::create_relin_keys makes the key of s^2 only, so this needs keys from
+                // elsewhere -- as in the reference.)
+                const std::size_t B = encrypted.batch(), rn = L * encrypted.poly_modulus_degree();
+                std::size_t size = encrypted.size();
+                const std::size_t stride = size * rn;
+                while (size > 2)
+                {
+                    const std::uint64_t *key = relin_keys.device_key(RelinKeys::get_index(size - 1));
+                    for (std::size_t b = 0; b < B; b++)
+                    {
+                        std::uint64_t *ct = encrypted.device_data() + b * stride;
+                        hip(moai_switch_key(dev(), ct, ct + (size - 1) * rn, key, L, 1, st()));
+                    }
+                    size--;
+                }
+                Ciphertext two;
+                two.resize_batch(context_, encrypted.parms_id(), 2, B);
+                for (std::size_t b = 0; b < B; b++)
+                {
+                    hip(moai_memcpy_d2d(two.device_data() + b * 2 * rn, encrypted.device_data() + b * stride, 2 * rn * 8, st()));
+                }
+                two.is_ntt_form() = true;
+                two.scale() = encrypted.scale();
+                encrypted = std::move(two);
+                return;
+            }
             Ciphertext out;
             out.resize_batch(context_, encrypted.parms_id(), 2, encrypted.batch());
             util::OpCombiner &comb = util::OpCombiner::instance();

@@ -960,6 +960,33 @@ void mo_ckks_multiply(const mo_context *c, uint64_t *x, const uint64_t *y, size_
     free(temp);
 }
 
+void mo_ckks_multiply_general(const mo_context *c, const uint64_t *x, size_t size_x, const uint64_t *y, size_t size_y, size_t L,
+                              uint64_t *out)
+{
+    /* SEAL/evaluator.cpp:862-900 (dest_size != 3): out[k] = sum over i + j = k of x[i] (*) y[j], the terms in increasing i,
+     * each product reduced and added into a zeroed accumulator. out: size_x + size_y - 1 polynomials, not an operand. */
+    const size_t n = c->n, dest = size_x + size_y - 1;
+    uint64_t *prod = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    memset(out, 0, sizeof(uint64_t) * dest * L * n);
+    for (size_t k = 0; k < dest; k++)
+    {
+        const size_t x_last = k < size_x - 1 ? k : size_x - 1;
+        const size_t y_first = k < size_y - 1 ? k : size_y - 1;
+        const size_t x_first = k - y_first;
+        for (size_t s = 0; s <= x_last - x_first; s++)
+        {
+            const uint64_t *xp = x + (x_first + s) * L * n, *yp = y + (y_first - s) * L * n;
+            for (size_t i = 0; i < L; i++)
+            {
+                uint64_t *acc = out + (k * L + i) * n;
+                mo_dyadic_product_coeffmod(xp + i * n, yp + i * n, n, &c->mods[i], prod);
+                mo_add_poly_coeffmod(prod, acc, n, &c->mods[i], acc);
+            }
+        }
+    }
+    free(prod);
+}
+
 void mo_ckks_square(const mo_context *c, uint64_t *x, size_t L)
 {
     /* SEAL/evaluator.cpp:1262-1274 */
@@ -1192,6 +1219,17 @@ void mo_relinearize(const mo_context *c, uint64_t *ct3, const uint64_t *relin_ke
 {
     /* SEAL/evaluator.cpp:1345-1400 for size 3 -> 2: switch_key(ct, c2, relin_keys[get_index(2)=0]) */
     mo_switch_key_inplace(c, ct3, ct3 + 2 * L * c->n, relin_key, L);
+}
+
+void mo_relinearize_general(const mo_context *c, uint64_t *ct, size_t size, size_t dest_size, const uint64_t *const *relin_keys, size_t L)
+{
+    /* SEAL/evaluator.cpp:1385-1393: while the size exceeds dest_size, the last polynomial is switched with
+     * relin_keys[get_index(size - 1)] = relin_keys[size - 3] into (c0, c1) and dropped. relin_keys[t]: the key for s^(t+2). */
+    while (size > dest_size && size > 2)
+    {
+        mo_switch_key_inplace(c, ct, ct + (size - 1) * L * c->n, relin_keys[size - 3], L);
+        size--;
+    }
 }
 
 void mo_apply_galois_inplace(const mo_context *c, uint64_t *ct, size_t L, uint32_t galois_elt,

@@ -138,6 +138,9 @@ void mo_mod_switch_drop(const mo_context *c, const uint64_t *in, size_t size, si
 void mo_ckks_multiply(const mo_context *c, uint64_t *x, const uint64_t *y, size_t L);
 /* SEAL/evaluator.cpp:1223-1282 */
 void mo_ckks_square(const mo_context *c, uint64_t *x, size_t L);
+/* SEAL/evaluator.cpp:862-900: the general product, out = size_x + size_y - 1 polynomials (not an operand) */
+void mo_ckks_multiply_general(const mo_context *c, const uint64_t *x, size_t size_x, const uint64_t *y, size_t size_y, size_t L,
+                              uint64_t *out);
 /* SEAL/evaluator.cpp:2336-2373: every poly of ct [size][L][N] (*)= plain [L][N] */
 void mo_multiply_plain(const mo_context *c, uint64_t *ct, size_t size, size_t L, const uint64_t *plain);
 /* add/sub/negate over [size][L][N] (SEAL/evaluator.cpp:130-350) */
@@ -153,6 +156,8 @@ void mo_switch_key_inplace(const mo_context *c, uint64_t *ct, const uint64_t *ta
                            size_t L);
 /* SEAL/evaluator.cpp:1345-1400: ct3 [3][L][N] -> ct2 [2][L][N] (first two polys of ct3, in place) */
 void mo_relinearize(const mo_context *c, uint64_t *ct3, const uint64_t *relin_key, size_t L);
+/* SEAL/evaluator.cpp:1345-1400 for any size: relin_keys[t] switches s^(t+2); the leading dest_size polynomials are the result */
+void mo_relinearize_general(const mo_context *c, uint64_t *ct, size_t size, size_t dest_size, const uint64_t *const *relin_keys, size_t L);
 /* SEAL/evaluator.cpp:2563-2665 (CKKS branch): ct [2][L][N] in place */
 void mo_apply_galois_inplace(const mo_context *c, uint64_t *ct, size_t L, uint32_t galois_elt,
                              const uint64_t *galois_key);

@@ -167,6 +167,36 @@ static void evaluator_ops()
     dec(c);
     for (size_t i = 0; i < slots; i++) e[i] = a[i] * b[i];
     CHECK(max_err(out, e, slots) < 1e-5);
+    // products of larger ciphertexts (the dest_size != 3 branch, SEAL/evaluator.cpp:862-900): 3 x 2 -> 4, the square of a
+    // size-3 ciphertext -> 5; relinearizing them needs the keys of s^3, s^4, which create_relin_keys does not make
+    {
+        Ciphertext c3, c4, c4b, c5;
+        vector<double> e2(slots);
+        evaluator.multiply(ca, cb, c3);
+        evaluator.multiply(c3, ca, c4);
+        CHECK(c4.size() == 4);
+        CHECK(fabs(c4.scale() / pow(2.0, 120) - 1.0) < 1e-9);
+        dec(c4);
+        for (size_t i = 0; i < slots; i++) e2[i] = a[i] * b[i] * a[i];
+        CHECK(max_err(out, e2, slots) < 1e-4);
+        evaluator.multiply(ca, c3, c4b);
+        CHECK(c4b.download() == c4.download());
+        evaluator.square(c3, c5);
+        CHECK(c5.size() == 5);
+        dec(c5);
+        for (size_t i = 0; i < slots; i++) e2[i] = a[i] * b[i] * a[i] * b[i];
+        CHECK(max_err(out, e2, slots) < 1e-4);
+        bool threw = false;
+        try
+        {
+            evaluator.relinearize_inplace(c4, rk);
+        }
+        catch (const std::invalid_argument &)
+        {
+            threw = true;
+        }
+        CHECK(threw);
+    }
     evaluator.relinearize_inplace(c, rk);
     CHECK(c.size() == 2);
     evaluator.rescale_to_next_inplace(c);

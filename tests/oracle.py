@@ -106,6 +106,8 @@ def _declare(L):
         "mo_mod_switch_drop": (None, [vp, vp, sz, sz, sz, vp]),
         "mo_ckks_multiply": (None, [vp, vp, vp, sz]),
         "mo_ckks_square": (None, [vp, vp, sz]),
+        "mo_ckks_multiply_general": (None, [vp, vp, sz, vp, sz, sz, vp]),
+        "mo_relinearize_general": (None, [vp, vp, sz, sz, vp, sz]),
         "mo_multiply_plain": (None, [vp, vp, sz, sz, vp]),
         "mo_ct_add": (None, [vp, vp, vp, sz, sz, vp]),
         "mo_ct_sub": (None, [vp, vp, vp, sz, sz, vp]),
@@ -240,6 +242,22 @@ class Context:
         y = np.ascontiguousarray(y, dtype=np.uint64)
         lib().mo_ckks_multiply(self.h, ptr(out), ptr(y), L)
         return out
+
+    def multiply_general(self, x, size_x, y, size_y, L):
+        """Evaluator::multiply for any sizes (SEAL/evaluator.cpp:862-900)"""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        y = np.ascontiguousarray(y, dtype=np.uint64)
+        out = np.empty((size_x + size_y - 1, L, self.n), dtype=np.uint64)
+        lib().mo_ckks_multiply_general(self.h, ptr(x), size_x, ptr(y), size_y, L, ptr(out))
+        return out
+
+    def relinearize_general(self, ct, size, dest_size, keys, L):
+        """Evaluator::relinearize_internal for any size; keys[t] is the switching key of s^(t+2)"""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64).copy()
+        keys = [np.ascontiguousarray(k, dtype=np.uint64) for k in keys]
+        arr = (C.c_void_p * len(keys))(*[k.ctypes.data for k in keys])
+        lib().mo_relinearize_general(self.h, ptr(ct), size, dest_size, arr, L)
+        return ct.reshape(size, L, self.n)[:dest_size].copy()
 
     def square(self, x, L):
         out = np.zeros((3, L, self.n), dtype=np.uint64)

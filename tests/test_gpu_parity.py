@@ -157,6 +157,40 @@ def test_ct_multiply_square(moai, env12):
         assert (got[b] == octx.square(x[b], L)).all()
 
 
+@pytest.mark.parametrize("sx,sy", [(2, 2), (3, 2), (2, 3), (3, 3), (4, 2), (5, 4)])
+def test_ct_multiply_general_sizes(moai, env12, sx, sy):
+    """Evaluator::multiply for operands that are not both of size 2 (SEAL/evaluator.cpp:862-900), batch 2, against the
+    oracle's restatement of that branch; edge residues 0 and q-1 in every polynomial"""
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    rng = np.random.default_rng(10 * sx + sy)
+    L, B = 3, 2
+    x = O.uniform_rns(rng, primes[:L], (B, sx), n)
+    y = O.uniform_rns(rng, primes[:L], (B, sy), n)
+    x[:, :, :, :4] = 0
+    for r in range(L):
+        x[:, :, r, 4:8] = primes[r] - 1
+        y[:, :, r, 4:12] = primes[r] - 1
+    do = moai.DeviceBuffer(B * (sx + sy - 1) * L * n)
+    ctx.ct_multiply_general(up(moai, x), sx, up(moai, y), sy, do, L, B)
+    got = do.to_numpy((B, sx + sy - 1, L, n))
+    for b in range(B):
+        assert (got[b] == octx.multiply_general(x[b], sx, y[b], sy, L)).all()
+    if (sx, sy) == (2, 2):
+        for b in range(B):
+            assert (got[b] == octx.multiply(x[b], y[b], L)).all()
+
+
+def test_ct_multiply_general_refuses_bad_sizes(moai, env12):
+    logn, primes, octx, ctx = env12
+    n = 1 << logn
+    buf = moai.DeviceBuffer(16 * 2 * n)
+    out = moai.DeviceBuffer(17 * 2 * n)
+    for sx, sy in ((1, 2), (2, 1), (9, 9), (16, 2)):
+        with pytest.raises(moai.hip.MoaiError):
+            ctx.ct_multiply_general(buf, sx, buf, sy, out, 2, 1)
+
+
 @pytest.mark.parametrize("count,bits", [(1, [51, 46, 58]), (17, [61, 60, 40]), (64, [51, 46, 46]), (100, [61, 61])])
 def test_ct_dot_matches_multiply_add_chain(moai, count, bits):
     # sum_j multiply(x[j], y[j]) as the reference issues it (Ct_ct_matrix_mul.hpp:33-42): one multiply and one
@@ -328,6 +362,26 @@ def test_switch_key_relin_galois(moai, env12, L, ks_arith):
         assert (ddst.to_numpy(ct.shape) == got).all()
         assert (dsrc.to_numpy(ct.shape) == ct).all()
     assert (d3.to_numpy(ct3.shape) == ct3).all()  # relinearize reads c0, c1 in its last kernel and leaves its input alone
+
+def test_relinearize_loop_over_sizes(moai, env12):
+    """relinearize_internal for a size-4 ciphertext (SEAL/evaluator.cpp:1385-1393) as the seal:: shim issues it: one
+    moai_switch_key per dropped polynomial, the key of s^3 first -- against the oracle's restatement of the loop"""
+    logn, primes, octx, ctx = env12
+    n, k = 1 << logn, len(primes)
+    rng = np.random.default_rng(44)
+    L = 3
+    keys = [O.uniform_rns(rng, primes, (k - 1, 2), n) for _ in range(2)]
+    dkeys = [up(moai, kk) for kk in keys]
+    ct4 = O.uniform_rns(rng, primes[:L], (4,), n)
+    want = octx.relinearize_general(ct4, 4, 2, keys, L)
+    d = up(moai, ct4)
+    rn = L * n
+    for size in (4, 3):
+        ctx.switch_key(d.ptr, d.ptr + (size - 1) * rn * 8, dkeys[size - 3], L, 1)
+    got = d.to_numpy((4, L, n))
+    assert (got[:2] == want).all()
+    assert (got[2:] == ct4[2:]).all()
+
 
 
 @pytest.mark.parametrize("bits", [[60, 50, 60, 61], [46, 58, 51, 58]])

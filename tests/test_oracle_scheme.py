@@ -60,6 +60,40 @@ def test_multiply_relinearize_rescale(env):
     assert max(abs(a - b) for a, b in zip(dsq, _negacyclic_mul(m1, m1, N))) < (1 << 52)
 
 
+def test_general_size_multiply_and_relinearize(env):
+    """Evaluator::multiply beyond 2 x 2 (SEAL/evaluator.cpp:862-900) and relinearize_internal's loop over sizes (:1385-1393),
+    by decryption -- the reference's own strategy for them -- and against the 2 x 2 restatement"""
+    ctx, cl = env
+    rng = np.random.default_rng(12)
+    L = 4
+    m1, m2, m3 = small_msg(rng, 30), small_msg(rng, 30), small_msg(rng, 30)
+    c1, c2, c3 = cl.encrypt(m1, L), cl.encrypt(m2, L), cl.encrypt(m3, L)
+    assert (ctx.multiply_general(c1, 2, c2, 2, L) == ctx.multiply(c1, c2, L)).all()
+    c12 = ctx.multiply(c1, c2, L)
+    c123 = ctx.multiply_general(c12, 3, c3, 2, L)
+    assert c123.shape == (4, L, N)
+    assert (ctx.multiply_general(c3, 2, c12, 3, L) == c123).all()  # commutative: exact sums mod q
+    want = _negacyclic_mul(_negacyclic_mul(m1, m2, N), m3, N)
+    d4 = cl.decrypt(c123, 4, L)
+    assert max(abs(a - b) for a, b in zip(d4, want)) < (1 << 80)  # noise ~ N^2 * 2^60 * e against 2^100 products
+    # (3 x 3): the square of a size-3 ciphertext is what ckks_square falls back to (:1237-1241)
+    c1212 = ctx.multiply_general(c12, 3, c12, 3, L)
+    p12 = _negacyclic_mul(m1, m2, N)
+    d5 = cl.decrypt(c1212, 5, L)
+    assert max(abs(a - b) for a, b in zip(d5, _negacyclic_mul(p12, p12, N))) < (1 << 110)
+    # size 4 -> 2 with the keys of s^2 and s^3 (RelinKeys::get_index(k) = k - 2, SEAL/relinkeys.h)
+    s2 = cl._dyadic(cl.s_ntt, cl.s_ntt, cl.k)
+    s3 = cl._dyadic(s2, cl.s_ntt, cl.k)
+    keys = [cl.kswitch_key(s2), cl.kswitch_key(s3)]
+    r2 = ctx.relinearize_general(c123, 4, 2, keys, L)
+    d2 = cl.decrypt(r2, 2, L)
+    assert max(abs(a - b) for a, b in zip(d2, d4)) < (1 << 20)
+    r3 = ctx.relinearize_general(c123, 4, 3, keys, L)
+    assert max(abs(a - b) for a, b in zip(cl.decrypt(r3, 3, L), d4)) < (1 << 20)
+    # the size-3 case of the loop is relinearize
+    assert (ctx.relinearize_general(c12, 3, 2, keys, L) == ctx.relinearize(c12, keys[0], L)).all()
+
+
 @pytest.mark.parametrize("L", [4, 3, 2, 1])
 def test_apply_galois_all_levels(env, L):
     ctx, cl = env

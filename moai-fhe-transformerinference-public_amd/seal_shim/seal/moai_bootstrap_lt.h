@@ -333,7 +333,8 @@ namespace moai_fused
             return static_cast<std::uint32_t>(diagonals_.size() / static_cast<std::size_t>(Nh_) - 1);
         }
 
-        // all non-zero baby steps in one moai_apply_galois_hoisted call; false when that form does not apply
+        // the first key switch of every non-zero baby step in one moai_apply_galois_hoisted call (for a step with its own key that
+        // is the whole rotation); false when that form does not apply
         bool hoisted_babies(const std::uint64_t *src, std::uint64_t *babies, std::size_t batch_words, std::size_t zero_baby, std::size_t L,
                             std::size_t B, const seal::GaloisKeys &keys) const
         {
@@ -363,8 +364,12 @@ namespace moai_fused
             const std::size_t count = zero_baby < nb ? nb - 1 : nb;
             std::vector<std::uint32_t> elts(count);
             std::vector<const std::uint64_t *> kptr(count), cptr(count);
-            std::vector<std::uint32_t> seq;
             std::vector<std::uint64_t *> optr(count);
+            // a step without its own key takes the NAF path of rotate_internal (SEAL/evaluator.cpp:2699-2721): several key
+            // switches in a row.  Its FIRST one still starts from the shared source and joins the hoisted call; the others
+            // follow in place.
+            std::vector<std::vector<std::uint32_t>> rest(count);
+            std::vector<std::uint32_t> seq;
             for (std::size_t k = 0, i = 0; k < nb; k++)
             {
                 if (k == zero_baby)
@@ -373,16 +378,12 @@ namespace moai_fused
                 }
                 seq.clear();
                 detail::rotation_sequence(context_, keys, baby_steps_[k], seq);
-                if (seq.size() != 1)
+                if (seq.empty())
                 {
-                    if (std::getenv("MOAI_SHIM_HOIST_DEBUG"))
-                    {
-                        std::fprintf(stderr, "[hoist] L=%zu: %zu baby steps, step %d takes %zu key switches: separate calls\n", L, nb,
-                                     baby_steps_[k], seq.size());
-                    }
-                    return false; // a step without its own key takes the NAF path of rotate_internal
+                    return false;
                 }
                 elts[i] = seq[0];
+                rest[i].assign(seq.begin() + 1, seq.end());
                 const std::size_t index = seal::GaloisKeys::get_index(seq[0]);
                 kptr[i] = keys.device_key(index);
                 cptr[i] = keys.hoist_correction(context_, index, seq[0], L);
@@ -392,6 +393,14 @@ namespace moai_fused
             int fell_back = 0;
             seal::util::hip_check(moai_apply_galois_hoisted(context_.device(), src, optr.data(), L, elts.data(), kptr.data(), cptr.data(), count, B,
                                                             &fell_back, context_.stream()));
+            for (std::size_t i = 0; i < count; i++)
+            {
+                for (std::uint32_t elt : rest[i])
+                {
+                    seal::util::hip_check(moai_apply_galois(context_.device(), optr[i], L, elt, keys.device_key(seal::GaloisKeys::get_index(elt)), B,
+                                                            context_.stream()));
+                }
+            }
             return true;
         }
 

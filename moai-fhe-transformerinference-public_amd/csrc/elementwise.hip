@@ -438,10 +438,15 @@ struct CtPtDotArgs
     uint16_t pi[CTPT_MAX_TERMS];
 };
 
+// P polynomials per thread: a plaintext value is loaded once and multiplied into P ciphertext polynomials (a plaintext row is
+// shared by the whole batch -- with one polynomial per thread it was fetched n_poly times).  blockIdx.y = group * L + prime, the
+// group holds polynomials group * P .. group * P + P - 1 (the last group may be short).
+template <int P>
 __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
 {
-    const uint32_t row = blockIdx.y; // poly * L + prime
-    const uint32_t prime = row % g.L;
+    const uint32_t prime = blockIdx.y % g.L;
+    const uint32_t poly0 = (blockIdx.y / g.L) * P;
+    const uint32_t np = g.n_poly - poly0 < (uint32_t)P ? g.n_poly - poly0 : (uint32_t)P; // uniform over the block
     const PrimeConst *pc = g.pc + prime;
     const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -451,26 +456,55 @@ __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
     }
     const size_t op_stride = (size_t)g.n_poly * g.L * g.n2;
     const size_t pt_stride = (size_t)g.L * g.n2;
-    const ulonglong2 *__restrict__ xb = reinterpret_cast<const ulonglong2 *>(g.x) + (size_t)row * g.n2 + i;
+    const size_t poly_stride = (size_t)g.L * g.n2;
+    const size_t row0 = ((size_t)poly0 * g.L + prime) * g.n2 + i;
+    const ulonglong2 *__restrict__ xb = reinterpret_cast<const ulonglong2 *>(g.x) + row0;
     const ulonglong2 *__restrict__ pb = reinterpret_cast<const ulonglong2 *>(g.p) + (size_t)prime * g.n2 + i;
-    uint64_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    uint64_t lo0[P], hi0[P], lo1[P], hi1[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+    {
+        lo0[k] = hi0[k] = lo1[k] = hi1[k] = 0;
+    }
     for (uint32_t t = 0; t < g.terms; ++t)
     {
-        const ulonglong2 a = xb[(size_t)g.xi[t] * op_stride];
         const ulonglong2 b = pb[(size_t)g.pi[t] * pt_stride];
-        mac128(lo0, hi0, a.x, b.x);
-        mac128(lo1, hi1, a.y, b.y);
+        const ulonglong2 *xt = xb + (size_t)g.xi[t] * op_stride;
+        ulonglong2 a[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+        {
+            a[k] = (uint32_t)k < np ? xt[(size_t)k * poly_stride] : make_ulonglong2(0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+        {
+            mac128(lo0[k], hi0[k], a[k].x, b.x);
+            mac128(lo1[k], hi1[k], a[k].y, b.y);
+        }
         if ((t & 31u) == 31u)
         {
-            lo0 = barrett128(lo0, hi0, q, cr0, cr1);
-            lo1 = barrett128(lo1, hi1, q, cr0, cr1);
-            hi0 = hi1 = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+            {
+                lo0[k] = barrett128(lo0[k], hi0[k], q, cr0, cr1);
+                lo1[k] = barrett128(lo1[k], hi1[k], q, cr0, cr1);
+                hi0[k] = hi1[k] = 0;
+            }
         }
     }
-    ulonglong2 r;
-    r.x = barrett128(lo0, hi0, q, cr0, cr1);
-    r.y = barrett128(lo1, hi1, q, cr0, cr1);
-    reinterpret_cast<ulonglong2 *>(g.out)[(size_t)row * g.n2 + i] = r;
+    ulonglong2 *ob = reinterpret_cast<ulonglong2 *>(g.out) + row0;
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+    {
+        if ((uint32_t)k < np)
+        {
+            ulonglong2 r;
+            r.x = barrett128(lo0[k], hi0[k], q, cr0, cr1);
+            r.y = barrett128(lo1[k], hi1[k], q, cr0, cr1);
+            ob[(size_t)k * poly_stride] = r;
+        }
+    }
 }
 
 static inline dim3 row_grid(const moai_ctx *c, size_t rows, uint32_t per_thread_chunks = 1)
@@ -842,8 +876,17 @@ extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p,
         g.xi[t] = (uint16_t)x_index[t];
         g.pi[t] = (uint16_t)p_index[t];
     }
-    MOAI_CHECK_GRID_ROWS(n_poly * L);
-    hipLaunchKernelGGL(ct_pt_dot_kernel, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
+    if (n_poly >= 4)
+    {
+        const size_t groups = (n_poly + 3) / 4;
+        MOAI_CHECK_GRID_ROWS(groups * L);
+        hipLaunchKernelGGL(ct_pt_dot_kernel<4>, row_grid(c, groups * L), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    else
+    {
+        MOAI_CHECK_GRID_ROWS(n_poly * L);
+        hipLaunchKernelGGL(ct_pt_dot_kernel<1>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
+    }
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
 }

@@ -181,6 +181,14 @@ int moai_rescale(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t size, 
  * coefficient.  Same residues as the two calls.  in: [batch][size][L][N], scalars[L] (host), out: [batch][size][L-1][N]. */
 int moai_mul_scalar_rescale(moai_ctx *ctx, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
                             size_t L, size_t batch, void *stream);
+/* moai_rescale / moai_mul_scalar_rescale followed by Evaluator::add_inplace (SEAL/evaluator.cpp:155-240) of `addend`, the
+ * addition done by the rescale's last kernel: what add_[inplace_]reduced_error of the fork issues after its level adjustment
+ * (SEAL/evaluator.cpp:447-480) and MOAI's polynomial evaluations issue per coefficient (rescale, then add to the running sum).
+ * Same residues as the separate calls.  addend: [batch][size][L-1][N], may be `out` itself (accumulate in place). */
+int moai_rescale_add(moai_ctx *ctx, const uint64_t *in, const uint64_t *addend, uint64_t *out, size_t size, size_t L,
+                     size_t batch, void *stream);
+int moai_mul_scalar_rescale_add(moai_ctx *ctx, const uint64_t *in, const uint64_t *scalars, const uint64_t *addend,
+                                uint64_t *out, size_t size, size_t L, size_t batch, void *stream);
 /* Evaluator::mod_switch_drop_to_next SEAL/evaluator.cpp:1483-1546 applied `drop` times:
  * in: [batch][size][L][N] -> out: [batch][size][L-drop][N].  out must not alias in (except batch*size == 1,
  * where the kept rows already are in place). */

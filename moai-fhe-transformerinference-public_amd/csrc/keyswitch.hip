@@ -739,49 +739,6 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
 
 using namespace moai;
 
-extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
-                            void *stream)
-{
-    trace_op("rescale", L, batch * size);
-    const size_t P = batch * size;
-    int rc = check_level(c, L, P);
-    if (rc)
-    {
-        return rc;
-    }
-    if (L < 2)
-    {
-        // SEAL/evaluator.cpp:1693-1696
-        return set_error(MOAI_EINVAL, "end of modulus switching chain reached");
-    }
-    if (P == 0)
-    {
-        return MOAI_OK;
-    }
-    if (!in || !out || in == out)
-    {
-        return set_error(MOAI_EINVAL, "bad in/out pointers");
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const size_t row_bytes = c->n * sizeof(uint64_t);
-    const size_t sz_last = align256(P * row_bytes);
-    const size_t sz_u = align256(P * (L - 1) * row_bytes);
-    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
-    void *wsp;
-    rc = workspace(c, sz_last + sz_u, s, &wsp);
-    if (rc)
-    {
-        return rc;
-    }
-    uint64_t *last = static_cast<uint64_t *>(wsp);
-    uint64_t *u = reinterpret_cast<uint64_t *>(static_cast<char *>(wsp) + sz_last);
-    MOAI_CHECK_GRID_ROWS(P);
-    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1),
-                       NO_ZERO, (uint32_t)(c->n >> 1));
-    MOAI_LAUNCH_CHECK();
-    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), nullptr, 0, 0, s);
-}
-
 namespace moai {
 // rows[r][:] = rows[r][:] * s mod q, canonical   (the dropped row of a fused scalar product + rescale)
 __global__ __launch_bounds__(256) void scale_rows_kernel(uint64_t *rows, Tw s, uint64_t q, uint32_t n2)
@@ -797,10 +754,11 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(uint64_t *rows, Tw s, u
 }
 } // namespace moai
 
-extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
-                                       size_t L, size_t batch, void *stream)
+// rescale_to_next (scalars == nullptr) or a scalar plaintext product followed by it, plus an optional addend of the output's
+// shape ([batch * size][L - 1][N]; may be `out` itself) that the last kernel adds to the quotient
+static int rescale_common(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, const uint64_t *addend, uint64_t *out, size_t size,
+                          size_t L, size_t batch, void *stream)
 {
-    trace_op("mul_scalar_rescale", L, batch * size);
     const size_t P = batch * size;
     int rc = check_level(c, L, P);
     if (rc)
@@ -809,21 +767,24 @@ extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const ui
     }
     if (L < 2)
     {
+        // SEAL/evaluator.cpp:1693-1696
         return set_error(MOAI_EINVAL, "end of modulus switching chain reached");
     }
     if (P == 0)
     {
         return MOAI_OK;
     }
-    if (!in || !out || !scalars || in == out)
+    if (!in || !out || in == out || in == addend)
     {
-        return set_error(MOAI_EINVAL, "bad pointers");
+        return set_error(MOAI_EINVAL, "bad in/out pointers");
     }
-    if (c->logn < 12)
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    if (scalars && c->logn < 12)
     {
         // small transforms take the two separate steps
         void *tmp = nullptr;
-        rc = moai_malloc(&tmp, P * L * c->n * sizeof(uint64_t));
+        rc = moai_malloc(&tmp, P * L * row_bytes);
         if (rc)
         {
             return rc;
@@ -831,22 +792,23 @@ extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const ui
         rc = moai_mul_scalar_rows(c, in, scalars, static_cast<uint64_t *>(tmp), P, L, stream);
         if (!rc)
         {
-            rc = moai_rescale(c, static_cast<const uint64_t *>(tmp), out, size, L, batch, stream);
+            rc = rescale_common(c, static_cast<const uint64_t *>(tmp), nullptr, addend, out, size, L, batch, stream);
         }
-        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        hipError_t e = hipStreamSynchronize(s);
         moai_free(tmp);
         return rc ? rc : (e == hipSuccess ? MOAI_OK : set_error(MOAI_EHIP, "%s", hipGetErrorString(e)));
     }
     Tw sc[MOAI_MAX_RNS];
-    for (size_t r = 0; r < L; r++)
+    if (scalars)
     {
-        const uint64_t q = c->primes[r];
-        const uint64_t v = scalars[r] % q; // barrett_reduce_64, polyarithsmallmod.h:209-217
-        sc[r].w = v;
-        sc[r].wq = (uint64_t)((((unsigned __int128)v) << 64) / q);
+        for (size_t r = 0; r < L; r++)
+        {
+            const uint64_t q = c->primes[r];
+            const uint64_t v = scalars[r] % q; // barrett_reduce_64, polyarithsmallmod.h:209-217
+            sc[r].w = v;
+            sc[r].wq = (uint64_t)((((unsigned __int128)v) << 64) / q);
+        }
     }
-    hipStream_t s = (hipStream_t)stream;
-    const size_t row_bytes = c->n * sizeof(uint64_t);
     const size_t sz_last = align256(P * row_bytes);
     const size_t sz_u = align256(P * (L - 1) * row_bytes);
     std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
@@ -861,10 +823,55 @@ extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const ui
     MOAI_CHECK_GRID_ROWS(P);
     hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, P), dim3(256), 0, s, in, last, 1u, (uint32_t)L, (uint32_t)(L - 1), NO_ZERO,
                        (uint32_t)(c->n >> 1));
-    MOAI_CHECK_GRID_ROWS(P);
-    hipLaunchKernelGGL(scale_rows_kernel, rgrid(c, P), dim3(256), 0, s, last, sc[L - 1], c->primes[L - 1], (uint32_t)(c->n >> 1));
+    if (scalars)
+    {
+        hipLaunchKernelGGL(scale_rows_kernel, rgrid(c, P), dim3(256), 0, s, last, sc[L - 1], c->primes[L - 1], (uint32_t)(c->n >> 1));
+    }
     MOAI_LAUNCH_CHECK();
-    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), nullptr, 0, 0, s, 1, 0, sc);
+    // the addend has the output's layout: polynomial p starts (L - 1) rows after polynomial p - 1 (ModDownArgs: pairs of
+    // polynomials 2 (L - 1) rows apart)
+    return moddown(c, last, in, (uint32_t)L, u, out, P, L - 1, (uint32_t)(L - 1), addend, (uint32_t)(2 * (L - 1)), addend ? 1 : 0, s, 1, 0,
+                   scalars ? sc : nullptr);
+}
+
+extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
+                            void *stream)
+{
+    trace_op("rescale", L, batch * size);
+    return rescale_common(c, in, nullptr, nullptr, out, size, L, batch, stream);
+}
+
+extern "C" int moai_rescale_add(moai_ctx *c, const uint64_t *in, const uint64_t *addend, uint64_t *out, size_t size, size_t L,
+                                size_t batch, void *stream)
+{
+    trace_op("rescale_add", L, batch * size);
+    if (!addend)
+    {
+        return set_error(MOAI_EINVAL, "null addend");
+    }
+    return rescale_common(c, in, nullptr, addend, out, size, L, batch, stream);
+}
+
+extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
+                                       size_t L, size_t batch, void *stream)
+{
+    trace_op("mul_scalar_rescale", L, batch * size);
+    if (!scalars)
+    {
+        return set_error(MOAI_EINVAL, "bad pointers");
+    }
+    return rescale_common(c, in, scalars, nullptr, out, size, L, batch, stream);
+}
+
+extern "C" int moai_mul_scalar_rescale_add(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, const uint64_t *addend,
+                                           uint64_t *out, size_t size, size_t L, size_t batch, void *stream)
+{
+    trace_op("mul_scalar_rescale_add", L, batch * size);
+    if (!scalars || !addend)
+    {
+        return set_error(MOAI_EINVAL, "bad pointers");
+    }
+    return rescale_common(c, in, scalars, addend, out, size, L, batch, stream);
 }
 
 extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,

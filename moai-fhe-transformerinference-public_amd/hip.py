@@ -53,6 +53,8 @@ SYMBOLS = {
     "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
     "moai_mul_scalar_rescale": (C.c_int, [vp, vp, u64p, vp, sz, sz, sz, vp]),
+    "moai_rescale_add": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, vp]),
+    "moai_mul_scalar_rescale_add": (C.c_int, [vp, vp, u64p, vp, vp, sz, sz, sz, vp]),
     "moai_mod_drop": (C.c_int, [vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_galois_permute": (C.c_int, [vp, vp, vp, sz, sz, C.c_uint32, vp]),
     "moai_galois_elt_from_step": (C.c_uint32, [vp, C.c_int]),
@@ -262,6 +264,13 @@ class Context:
     def mul_scalar_rescale(self, src, scalars, out, size, L, batch, stream=None):
         s = (C.c_uint64 * L)(*[int(x) for x in scalars])
         _check(lib().moai_mul_scalar_rescale(self.h, _ptr(src), s, _ptr(out), size, L, batch, stream))
+
+    def rescale_add(self, src, addend, out, size, L, batch, stream=None):
+        _check(lib().moai_rescale_add(self.h, _ptr(src), _ptr(addend), _ptr(out), size, L, batch, stream))
+
+    def mul_scalar_rescale_add(self, src, scalars, addend, out, size, L, batch, stream=None):
+        s = (C.c_uint64 * L)(*[int(x) for x in scalars])
+        _check(lib().moai_mul_scalar_rescale_add(self.h, _ptr(src), s, _ptr(addend), _ptr(out), size, L, batch, stream))
 
     def mod_drop(self, src, out, size, L, drop, batch, stream=None):
         _check(lib().moai_mod_drop(self.h, _ptr(src), _ptr(out), size, L, drop, batch, stream))

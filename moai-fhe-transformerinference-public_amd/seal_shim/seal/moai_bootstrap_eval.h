@@ -365,14 +365,15 @@ namespace moai_fused
                         {
                             continue;
                         }
-                        if (j < heap_k)
+                        const Ciphertext &term = j < heap_k ? baby[static_cast<std::size_t>(j)] : giant[0];
+                        if (evaluator.rides_on_rescale_of(h, term))
                         {
-                            evaluator.multiply_const_rescale(baby[static_cast<std::size_t>(j)], node.cheb[static_cast<std::size_t>(j)], tmp);
+                            // the product lands on h's level: add_reduced_error would be a plain addition (same level: the scale
+                            // of the new term is taken, evaluator.cpp:447-452), and it rides on the rescale
+                            evaluator.multiply_const_rescale(term, node.cheb[static_cast<std::size_t>(j)], h, 0, &h);
+                            continue;
                         }
-                        else
-                        {
-                            evaluator.multiply_const_rescale(giant[0], node.cheb[static_cast<std::size_t>(j)], tmp);
-                        }
+                        evaluator.multiply_const_rescale(term, node.cheb[static_cast<std::size_t>(j)], tmp);
                         evaluator.add_reduced_error(h, tmp, h);
                     }
                 }
@@ -398,8 +399,20 @@ namespace moai_fused
                         else
                         {
                             evaluator.multiply_reduced_error(cipherheap[q], giant[gindex], relin_keys, h);
-                            evaluator.rescale_to_next_inplace(h);
-                            evaluator.add_reduced_error(h, cipherheap[r], h);
+                            if (evaluator.rides_on_rescale_of(cipherheap[r], h))
+                            {
+                                // rescale, then an addition at equal levels (which takes the second operand's scale): one pass,
+                                // accumulated into the remainder's buffer, which nothing reads after this
+                                const double keep = cipherheap[r].scale();
+                                evaluator.rescale_to_next_add_inplace(h, cipherheap[r]);
+                                cipherheap[r].scale() = keep;
+                                h = std::move(cipherheap[r]);
+                            }
+                            else
+                            {
+                                evaluator.rescale_to_next_inplace(h);
+                                evaluator.add_reduced_error(h, cipherheap[r], h);
+                            }
                         }
                     }
                 }

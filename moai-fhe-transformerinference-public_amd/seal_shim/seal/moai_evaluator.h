@@ -404,6 +404,30 @@ namespace seal
             out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus().back().value());
             destination = std::move(out);
         }
+        // true when `addend` can ride on the last kernel of a rescale of `encrypted` (moai_rescale_add / moai_mul_scalar_rescale_add):
+        // it sits one level below, with the same shape -- the case in which the add_inplace that would follow adds
+        // polynomial to polynomial (SEAL/evaluator.cpp:198-214)
+        bool rides_on_rescale_of(const Ciphertext &addend, const Ciphertext &encrypted) const
+        {
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            return cd && cd->next_context_data() && addend.parms_id() == cd->next_context_data()->parms_id() && addend.is_ntt_form() &&
+                   encrypted.is_ntt_form() && addend.size() == encrypted.size() && addend.batch() == encrypted.batch() &&
+                   addend.device_data() != encrypted.device_data();
+        }
+        // acc = rescale_to_next(encrypted) + acc in one pass, acc one level below `encrypted` (rides_on_rescale_of): the
+        // pair rescale_to_next_inplace + add_inplace; acc takes the rescaled scale like add_*_reduced_error gives it
+        void rescale_to_next_add_inplace(const Ciphertext &encrypted, Ciphertext &acc) const
+        {
+            check_ct(encrypted, "encrypted");
+            if (!rides_on_rescale_of(acc, encrypted))
+            {
+                throw std::invalid_argument("acc does not sit one level below encrypted with its shape");
+            }
+            auto cd = context_.get_context_data(encrypted.parms_id());
+            hip(moai_rescale_add(dev(), encrypted.device_data(), acc.device_data(), acc.device_data(), encrypted.size(),
+                                 encrypted.coeff_modulus_size(), encrypted.batch(), st()));
+            acc.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus().back().value());
+        }
         void rescale_to_next_inplace(Ciphertext &encrypted, MemoryPoolHandle = MemoryPoolHandle()) const
         {
             Ciphertext out;
@@ -611,7 +635,10 @@ namespace seal
         // over the ciphertext (moai_mul_scalar_rescale); not part of the reference's interface, same result as the
         // two calls.  forced_scale > 0 replaces the product's scale before the rescale divides it (the
         // *_reduced_error compositions overwrite the scale between the two calls, SEAL/evaluator.cpp:447-452).
-        void multiply_const_rescale(const Ciphertext &encrypted, double value, Ciphertext &destination, double forced_scale = 0) const
+        // `addend` (optional; may be `destination` itself): a ciphertext one level below `encrypted` that is added to the result
+        // by the same pass (rides_on_rescale_of) -- multiply_const, rescale_to_next_inplace, add_inplace in one call
+        void multiply_const_rescale(const Ciphertext &encrypted, double value, Ciphertext &destination, double forced_scale = 0,
+                                    const Ciphertext *addend = nullptr) const
         {
             Plaintext const_plain;
             encoder_.encode(value, encrypted.scale(), const_plain);
@@ -633,24 +660,53 @@ namespace seal
             {
                 throw std::invalid_argument("end of modulus switching chain reached");
             }
+            if (addend && !rides_on_rescale_of(*addend, encrypted))
+            {
+                throw std::invalid_argument("addend does not sit one level below encrypted with its shape");
+            }
             if (!const_plain.is_scalar())
             {
-                multiply_plain(encrypted, const_plain, destination);
+                Ciphertext product;
+                multiply_plain(encrypted, const_plain, product);
                 if (forced_scale > 0)
                 {
-                    destination.scale() = forced_scale;
+                    product.scale() = forced_scale;
                 }
-                rescale_to_next_inplace(destination);
+                rescale_to_next_inplace(product);
+                if (addend)
+                {
+                    Ciphertext sum = *addend;
+                    sum.scale() = product.scale();
+                    add_inplace(sum, product);
+                    product = std::move(sum);
+                }
+                destination = std::move(product);
                 return;
             }
             auto next = cd->next_context_data();
             const std::size_t L = encrypted.coeff_modulus_size();
+            const double out_scale = (forced_scale > 0 ? forced_scale : new_scale) / static_cast<double>(cd->parms().coeff_modulus().back().value());
+            if (addend && addend == &destination)
+            {
+                hip(moai_mul_scalar_rescale_add(dev(), encrypted.device_data(), const_plain.scalar_rows().data(), destination.device_data(),
+                                                destination.device_data(), encrypted.size(), L, encrypted.batch(), st()));
+                destination.scale() = out_scale;
+                return;
+            }
             Ciphertext out;
             out.resize_batch(context_, next->parms_id(), encrypted.size(), encrypted.batch());
-            hip(moai_mul_scalar_rescale(dev(), encrypted.device_data(), const_plain.scalar_rows().data(), out.device_data(), encrypted.size(), L,
-                                        encrypted.batch(), st()));
+            if (addend)
+            {
+                hip(moai_mul_scalar_rescale_add(dev(), encrypted.device_data(), const_plain.scalar_rows().data(), addend->device_data(),
+                                                out.device_data(), encrypted.size(), L, encrypted.batch(), st()));
+            }
+            else
+            {
+                hip(moai_mul_scalar_rescale(dev(), encrypted.device_data(), const_plain.scalar_rows().data(), out.device_data(), encrypted.size(), L,
+                                            encrypted.batch(), st()));
+            }
             out.is_ntt_form() = true;
-            out.scale() = (forced_scale > 0 ? forced_scale : new_scale) / static_cast<double>(cd->parms().coeff_modulus().back().value());
+            out.scale() = out_scale;
             destination = std::move(out);
         }
         template <typename T>
@@ -1063,6 +1119,12 @@ namespace seal
                 double q_last = static_cast<double>(cd->parms().coeff_modulus()[c2 - 1].value());
                 Ciphertext adjusted;
                 double scale_adjust = encrypted1.scale() * q_last / (encrypted2.scale() * encrypted2.scale());
+                if (op == 0 && c2 == c1 + 1 && rides_on_rescale_of(encrypted1, encrypted2))
+                {
+                    // the adjusted operand lands on encrypted1's level: the addition rides on its rescale
+                    multiply_const_rescale(encrypted2, scale_adjust, encrypted1, encrypted1.scale() * q_last, &encrypted1);
+                    return;
+                }
                 multiply_const_rescale(encrypted2, scale_adjust, adjusted, encrypted1.scale() * q_last);
                 mod_switch_to_inplace(adjusted, encrypted1.parms_id());
                 encrypted1.scale() = adjusted.scale();
@@ -1078,6 +1140,13 @@ namespace seal
                 double q_last = static_cast<double>(cd->parms().coeff_modulus()[c1 - 1].value());
                 Ciphertext adjusted;
                 double scale_adjust = encrypted2.scale() * q_last / (encrypted1.scale() * encrypted1.scale());
+                if (op == 0 && c1 == c2 + 1 && rides_on_rescale_of(encrypted2, encrypted1))
+                {
+                    multiply_const_rescale(encrypted1, scale_adjust, adjusted, encrypted2.scale() * q_last, &encrypted2);
+                    adjusted.scale() = encrypted2.scale();
+                    encrypted1 = std::move(adjusted);
+                    return;
+                }
                 multiply_const_rescale(encrypted1, scale_adjust, adjusted, encrypted2.scale() * q_last);
                 mod_switch_to_inplace(adjusted, encrypted2.parms_id());
                 adjusted.scale() = encrypted2.scale();

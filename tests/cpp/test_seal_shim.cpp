@@ -340,6 +340,63 @@ static void evaluator_ops()
         dec(r);
         for (size_t i = 0; i < slots; i++) e[i] = a[i] + b[i];
         CHECK(max_err(out, e, slots) < 1e-4);
+        // ... and bit for bit against the definition of add_inplace_reduced_error (fork, SEAL/evaluator.cpp:447-480) spelled
+        // with the primitive calls: the shim lets the final addition ride on the rescale of the level adjustment
+        // (moai_mul_scalar_rescale_add), in both operand orders
+        {
+            auto spelled = [&](const Ciphertext &high, const Ciphertext &low, bool high_first) {
+                const double q_last = (double)context.get_context_data(high.parms_id())->parms().coeff_modulus().back().value();
+                const double adjust = low.scale() * q_last / (high.scale() * high.scale());
+                Plaintext padj;
+                encoder.encode(adjust, high.scale(), padj);
+                evaluator.mod_switch_to_inplace(padj, high.parms_id());
+                Ciphertext t;
+                evaluator.multiply_plain(high, padj, t);
+                t.scale() = low.scale() * q_last;
+                evaluator.rescale_to_next_inplace(t);
+                Ciphertext res;
+                if (high_first)
+                {
+                    // encrypted1 is the higher one: adjusted takes encrypted2's scale, then += encrypted2
+                    t.scale() = low.scale();
+                    evaluator.add_inplace(t, low);
+                    res = t;
+                }
+                else
+                {
+                    // encrypted1 is the lower one: it takes adjusted's scale, then += adjusted
+                    res = low;
+                    res.scale() = t.scale();
+                    evaluator.add_inplace(res, t);
+                }
+                return res;
+            };
+            Ciphertext want = spelled(ca, lo, true), got;
+            evaluator.add_reduced_error(ca, lo, got);
+            CHECK(got.parms_id() == want.parms_id() && got.scale() == want.scale());
+            CHECK(got.download() == want.download());
+            want = spelled(ca, lo, false);
+            evaluator.add_reduced_error(lo, ca, got);
+            CHECK(got.parms_id() == want.parms_id() && got.scale() == want.scale());
+            CHECK(got.download() == want.download());
+            // the accumulate form used by the polynomial evaluations: acc += rescale(x * c), and acc = rescale(x) + acc
+            Ciphertext acc = lo, t2;
+            evaluator.multiply_const_rescale(ca, 0.75, t2);
+            Ciphertext ref = lo;
+            ref.scale() = t2.scale();
+            evaluator.add_inplace(ref, t2);
+            CHECK(evaluator.rides_on_rescale_of(acc, ca));
+            evaluator.multiply_const_rescale(ca, 0.75, acc, 0, &acc);
+            CHECK(acc.scale() == ref.scale() && acc.download() == ref.download());
+            acc = lo;
+            evaluator.rescale_to_next(ca, t2);
+            ref = lo;
+            ref.scale() = t2.scale();
+            evaluator.add_inplace(ref, t2);
+            evaluator.rescale_to_next_add_inplace(ca, acc);
+            CHECK(acc.scale() == ref.scale() && acc.download() == ref.download());
+            CHECK(!evaluator.rides_on_rescale_of(ca, ca) && !evaluator.rides_on_rescale_of(ca, lo));
+        }
         evaluator.sub_reduced_error(lo, ca, r);
         dec(r);
         for (size_t i = 0; i < slots; i++) e[i] = b[i] - a[i];

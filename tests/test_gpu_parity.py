@@ -303,6 +303,23 @@ def test_scalar_product_fused_into_rescale(moai, logn, bits, ks_arith):
             prod[:, :, i, :] = (prod[:, :, i, :].astype(object) * (scalars[i] % q) % q).astype(np.uint64)
         for b in range(B):
             assert (want[b] == octx.rescale(prod[b], size, L)).all(), (L, b)
+        # the same with the addition that follows (add_inplace of the running sum, SEAL/evaluator.cpp:155-240) done by the
+        # rescale's last kernel: separate destination, and accumulating in place; edge residues q-1 in the addend
+        acc = O.uniform_rns(rng, primes[: L - 1], (B, size), n)
+        for i in range(L - 1):
+            acc[:, :, i, :16] = primes[i] - 1
+        expect = np.stack([octx.add(want[b], acc[b], size, L - 1).reshape(size, L - 1, n) for b in range(B)])
+        dacc, out = up(moai, acc), moai.DeviceBuffer(acc.size)
+        ctx.mul_scalar_rescale_add(dx, scalars, dacc, out, size, L, B)
+        assert (out.to_numpy(acc.shape) == expect).all(), L
+        assert (dacc.to_numpy(acc.shape) == acc).all()
+        ctx.mul_scalar_rescale_add(dx, scalars, dacc, dacc, size, L, B)
+        assert (dacc.to_numpy(acc.shape) == expect).all(), L
+        dacc = up(moai, acc)
+        ctx.rescale_add(dprod, dacc, out, size, L, B)
+        assert (out.to_numpy(acc.shape) == expect).all(), L
+        ctx.rescale_add(dprod, dacc, dacc, size, L, B)
+        assert (dacc.to_numpy(acc.shape) == expect).all(), L
 
 
 def test_galois_permute(moai, env12):

@@ -156,6 +156,13 @@ int moai_ct_dot(moai_ctx *ctx, const uint64_t *x, const uint64_t *y, uint64_t *o
  * arrays.  terms <= 64.  Same canonical residues as the reference's multiply-reduce-add sequence. */
 int moai_ct_pt_dot(moai_ctx *ctx, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
                    const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream);
+/* Two such sums over the same operands in one pass -- two giant steps of one transform (Bootstrapper.cpp:2024-2062): every
+ * baby-step ciphertext is read once for both.  out = sum over t < terms of x[x_index[t]] (.) p[p_index[t]];
+ * out2 = sum over t < terms2 <= terms of x[x_index[t]] (.) p[p_index2[t]] (the last giant step of a transform is shorter).
+ * The same residues as two moai_ct_pt_dot calls. */
+int moai_ct_pt_dot2(moai_ctx *ctx, const uint64_t *x, const uint64_t *p, uint64_t *out, uint64_t *out2,
+                    const uint32_t *x_index, const uint32_t *p_index, const uint32_t *p_index2, size_t terms, size_t terms2,
+                    size_t n_poly, size_t L, void *stream);
 
 /*
  * Column-packed ciphertext x plaintext matrix product with scalar-encoded weights: the body of

@@ -436,12 +436,17 @@ struct CtPtDotArgs
     uint32_t terms, L, n2, n_poly;
     uint16_t xi[CTPT_MAX_TERMS];
     uint16_t pi[CTPT_MAX_TERMS];
+    // a second sum over the leading terms2 <= terms operands with its own plaintexts (moai_ct_pt_dot2): the operands are
+    // loaded once for both
+    uint64_t *out2;
+    uint32_t terms2;
+    uint16_t pi2[CTPT_MAX_TERMS];
 };
 
 // P polynomials per thread: a plaintext value is loaded once and multiplied into P ciphertext polynomials (a plaintext row is
 // shared by the whole batch -- with one polynomial per thread it was fetched n_poly times).  blockIdx.y = group * L + prime, the
 // group holds polynomials group * P .. group * P + P - 1 (the last group may be short).
-template <int P>
+template <int P, bool TWO>
 __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
 {
     const uint32_t prime = blockIdx.y % g.L;
@@ -460,15 +465,26 @@ __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
     const size_t row0 = ((size_t)poly0 * g.L + prime) * g.n2 + i;
     const ulonglong2 *__restrict__ xb = reinterpret_cast<const ulonglong2 *>(g.x) + row0;
     const ulonglong2 *__restrict__ pb = reinterpret_cast<const ulonglong2 *>(g.p) + (size_t)prime * g.n2 + i;
-    uint64_t lo0[P], hi0[P], lo1[P], hi1[P];
+    constexpr int S = TWO ? 2 : 1;
+    uint64_t lo0[S][P], hi0[S][P], lo1[S][P], hi1[S][P];
 #pragma unroll
-    for (int k = 0; k < P; ++k)
+    for (int s = 0; s < S; ++s)
     {
-        lo0[k] = hi0[k] = lo1[k] = hi1[k] = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+        {
+            lo0[s][k] = hi0[s][k] = lo1[s][k] = hi1[s][k] = 0;
+        }
     }
     for (uint32_t t = 0; t < g.terms; ++t)
     {
         const ulonglong2 b = pb[(size_t)g.pi[t] * pt_stride];
+        const bool second = TWO && t < g.terms2; // uniform
+        ulonglong2 b2 = make_ulonglong2(0, 0);
+        if (second)
+        {
+            b2 = pb[(size_t)g.pi2[t] * pt_stride];
+        }
         const ulonglong2 *xt = xb + (size_t)g.xi[t] * op_stride;
         ulonglong2 a[P];
 #pragma unroll
@@ -479,30 +495,43 @@ __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
 #pragma unroll
         for (int k = 0; k < P; ++k)
         {
-            mac128(lo0[k], hi0[k], a[k].x, b.x);
-            mac128(lo1[k], hi1[k], a[k].y, b.y);
+            mac128(lo0[0][k], hi0[0][k], a[k].x, b.x);
+            mac128(lo1[0][k], hi1[0][k], a[k].y, b.y);
+            if (TWO)
+            {
+                mac128(lo0[S - 1][k], hi0[S - 1][k], a[k].x, b2.x); // b2 = 0 past terms2
+                mac128(lo1[S - 1][k], hi1[S - 1][k], a[k].y, b2.y);
+            }
         }
         if ((t & 31u) == 31u)
         {
 #pragma unroll
-            for (int k = 0; k < P; ++k)
+            for (int s = 0; s < S; ++s)
             {
-                lo0[k] = barrett128(lo0[k], hi0[k], q, cr0, cr1);
-                lo1[k] = barrett128(lo1[k], hi1[k], q, cr0, cr1);
-                hi0[k] = hi1[k] = 0;
+#pragma unroll
+                for (int k = 0; k < P; ++k)
+                {
+                    lo0[s][k] = barrett128(lo0[s][k], hi0[s][k], q, cr0, cr1);
+                    lo1[s][k] = barrett128(lo1[s][k], hi1[s][k], q, cr0, cr1);
+                    hi0[s][k] = hi1[s][k] = 0;
+                }
             }
         }
     }
-    ulonglong2 *ob = reinterpret_cast<ulonglong2 *>(g.out) + row0;
 #pragma unroll
-    for (int k = 0; k < P; ++k)
+    for (int s = 0; s < S; ++s)
     {
-        if ((uint32_t)k < np)
+        ulonglong2 *ob = reinterpret_cast<ulonglong2 *>(s == 0 ? g.out : g.out2) + row0;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
         {
-            ulonglong2 r;
-            r.x = barrett128(lo0[k], hi0[k], q, cr0, cr1);
-            r.y = barrett128(lo1[k], hi1[k], q, cr0, cr1);
-            ob[(size_t)k * poly_stride] = r;
+            if ((uint32_t)k < np)
+            {
+                ulonglong2 r;
+                r.x = barrett128(lo0[s][k], hi0[s][k], q, cr0, cr1);
+                r.y = barrett128(lo1[s][k], hi1[s][k], q, cr0, cr1);
+                ob[(size_t)k * poly_stride] = r;
+            }
         }
     }
 }
@@ -830,24 +859,24 @@ extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, ui
     return MOAI_OK;
 }
 
-extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
-                              const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream)
+static int ct_pt_dot_common(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, uint64_t *out2, const uint32_t *x_index,
+                            const uint32_t *p_index, const uint32_t *p_index2, size_t terms, size_t terms2, size_t n_poly, size_t L,
+                            void *stream)
 {
-    trace_op("ct_pt_dot", L, n_poly * terms);
     int rc = check_rows(c, n_poly, L);
     if (rc)
     {
         return rc;
     }
-    if (terms == 0 || terms > CTPT_MAX_TERMS)
+    if (terms == 0 || terms > CTPT_MAX_TERMS || (out2 && (terms2 == 0 || terms2 > terms)))
     {
-        return set_error(MOAI_EINVAL, "between 1 and 64 terms per call");
+        return set_error(MOAI_EINVAL, "between 1 and 64 terms per call (the second sum over a leading part of them)");
     }
     if (n_poly == 0)
     {
         return MOAI_OK;
     }
-    if (!x || !p || !out || !x_index || !p_index)
+    if (!x || !p || !out || !x_index || !p_index || (out2 && (!p_index2 || out2 == out)))
     {
         return set_error(MOAI_EINVAL, "null argument");
     }
@@ -862,33 +891,70 @@ extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p,
     g.x = x;
     g.p = p;
     g.out = out;
+    g.out2 = out2;
     g.pc = c->pc;
     g.terms = (uint32_t)terms;
+    g.terms2 = (uint32_t)(out2 ? terms2 : 0);
     g.L = (uint32_t)L;
     g.n2 = (uint32_t)(c->n >> 1);
     g.n_poly = (uint32_t)n_poly;
     for (size_t t = 0; t < terms; t++)
     {
-        if (x_index[t] > 0xffffu || p_index[t] > 0xffffu)
+        if (x_index[t] > 0xffffu || p_index[t] > 0xffffu || (out2 && t < terms2 && p_index2[t] > 0xffffu))
         {
             return set_error(MOAI_EINVAL, "operand index out of range");
         }
         g.xi[t] = (uint16_t)x_index[t];
         g.pi[t] = (uint16_t)p_index[t];
+        g.pi2[t] = (uint16_t)(out2 && t < terms2 ? p_index2[t] : 0);
     }
+    hipStream_t s = (hipStream_t)stream;
     if (n_poly >= 4)
     {
         const size_t groups = (n_poly + 3) / 4;
         MOAI_CHECK_GRID_ROWS(groups * L);
-        hipLaunchKernelGGL(ct_pt_dot_kernel<4>, row_grid(c, groups * L), dim3(256), 0, (hipStream_t)stream, g);
+        if (out2)
+        {
+            hipLaunchKernelGGL((ct_pt_dot_kernel<4, true>), row_grid(c, groups * L), dim3(256), 0, s, g);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ct_pt_dot_kernel<4, false>), row_grid(c, groups * L), dim3(256), 0, s, g);
+        }
     }
     else
     {
         MOAI_CHECK_GRID_ROWS(n_poly * L);
-        hipLaunchKernelGGL(ct_pt_dot_kernel<1>, row_grid(c, n_poly * L), dim3(256), 0, (hipStream_t)stream, g);
+        if (out2)
+        {
+            hipLaunchKernelGGL((ct_pt_dot_kernel<1, true>), row_grid(c, n_poly * L), dim3(256), 0, s, g);
+        }
+        else
+        {
+            hipLaunchKernelGGL((ct_pt_dot_kernel<1, false>), row_grid(c, n_poly * L), dim3(256), 0, s, g);
+        }
     }
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
+}
+
+extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
+                              const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream)
+{
+    trace_op("ct_pt_dot", L, n_poly * terms);
+    return ct_pt_dot_common(c, x, p, out, nullptr, x_index, p_index, nullptr, terms, 0, n_poly, L, stream);
+}
+
+extern "C" int moai_ct_pt_dot2(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, uint64_t *out2,
+                               const uint32_t *x_index, const uint32_t *p_index, const uint32_t *p_index2, size_t terms, size_t terms2,
+                               size_t n_poly, size_t L, void *stream)
+{
+    trace_op("ct_pt_dot", L, n_poly * (terms + terms2)); // the same products as two moai_ct_pt_dot calls
+    if (!out2)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    return ct_pt_dot_common(c, x, p, out, out2, x_index, p_index, p_index2, terms, terms2, n_poly, L, stream);
 }
 
 extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,

@@ -50,6 +50,7 @@ SYMBOLS = {
     "moai_ct_multiply_general": (C.c_int, [vp, vp, sz, vp, sz, vp, sz, sz, vp]),
     "moai_ct_dot": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_pt_dot": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, vp]),
+    "moai_ct_pt_dot2": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, sz, vp]),
     "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
     "moai_mul_scalar_rescale": (C.c_int, [vp, vp, u64p, vp, sz, sz, sz, vp]),
@@ -254,6 +255,13 @@ class Context:
         xi = (C.c_uint32 * len(x_index))(*[int(v) for v in x_index])
         pi = (C.c_uint32 * len(p_index))(*[int(v) for v in p_index])
         _check(lib().moai_ct_pt_dot(self.h, _ptr(x), _ptr(p), _ptr(out), xi, pi, len(x_index), n_poly, L, stream))
+
+    def ct_pt_dot2(self, x, p, out, out2, x_index, p_index, p_index2, n_poly, L, stream=None):
+        xi = (C.c_uint32 * len(x_index))(*[int(v) for v in x_index])
+        pi = (C.c_uint32 * len(p_index))(*[int(v) for v in p_index])
+        pi2 = (C.c_uint32 * max(1, len(p_index2)))(*[int(v) for v in p_index2])
+        _check(lib().moai_ct_pt_dot2(self.h, _ptr(x), _ptr(p), _ptr(out), _ptr(out2), xi, pi, pi2, len(x_index), len(p_index2), n_poly, L,
+                                     stream))
 
     def ct_pt_matmul(self, x, w, out, rows, cols, size, L, stream=None):
         _check(lib().moai_ct_pt_matmul(self.h, _ptr(x), _ptr(w), _ptr(out), rows, cols, size, L, stream))

@@ -15,6 +15,7 @@
 // Modular sums are associative, so the order of the additions does not matter for the residues; scale and
 // level bookkeeping follow the reference (product scale = input scale squared, level unchanged).
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -285,15 +286,17 @@ namespace moai_fused
                     rotate_batch_from(src, dst, baby_steps_[k], L, B, gal_keys, seq);
                 }
             }
-            util::DeviceArray acc(batch_words, st), giant(batch_words, st);
+            // Giant steps two at a time where their baby-step lists nest (all of a transform's giant steps use the same babies,
+            // the last one a leading part of them): one pass over the babies feeds both inner sums (moai_ct_pt_dot2).
+            // MOAI_SHIM_DOT2=0 keeps one moai_ct_pt_dot per giant step.
+            static const bool pairs = [] {
+                const char *e = std::getenv("MOAI_SHIM_DOT2");
+                return !(e && e[0] == '0');
+            }();
+            util::DeviceArray acc(batch_words, st), giant(batch_words, st), giant2;
             bool first = true;
-            std::vector<std::uint32_t> xi, pi;
-            for (auto &g : giants_)
-            {
-                std::uint64_t *dst = first && g.step == 0 ? acc.get() : giant.get();
-                xi.assign(g.baby.begin(), g.baby.end());
-                pi.assign(g.diag.begin(), g.diag.end());
-                util::hip_check(moai_ct_pt_dot(dev, babies.get(), plain, dst, xi.data(), pi.data(), xi.size(), B * 2, L, st));
+            std::vector<std::uint32_t> xi, pi, pi2;
+            auto fold = [&](std::uint64_t *dst, const Giant &g) {
                 if (g.step != 0)
                 {
                     rotate_batch(dst, g.step, L, B, gal_keys, seq);
@@ -310,6 +313,38 @@ namespace moai_fused
                 {
                     util::hip_check(moai_add(dev, acc.get(), dst, acc.get(), B * 2, L, st));
                 }
+            };
+            auto leads = [](const Giant &shorter, const Giant &longer) {
+                return shorter.baby.size() <= longer.baby.size() && std::equal(shorter.baby.begin(), shorter.baby.end(), longer.baby.begin());
+            };
+            for (std::size_t k = 0; k < giants_.size();)
+            {
+                const Giant &ga = giants_[k];
+                std::uint64_t *dst = first && ga.step == 0 ? acc.get() : giant.get();
+                const Giant *gb = pairs && k + 1 < giants_.size() ? &giants_[k + 1] : nullptr;
+                if (gb && (leads(*gb, ga) || leads(ga, *gb)))
+                {
+                    if (!giant2.get())
+                    {
+                        giant2.resize(batch_words, st);
+                    }
+                    const bool a_long = leads(*gb, ga);
+                    const Giant &lng = a_long ? ga : *gb, &sht = a_long ? *gb : ga;
+                    xi.assign(lng.baby.begin(), lng.baby.end());
+                    pi.assign(lng.diag.begin(), lng.diag.end());
+                    pi2.assign(sht.diag.begin(), sht.diag.end());
+                    util::hip_check(moai_ct_pt_dot2(dev, babies.get(), plain, a_long ? dst : giant2.get(), a_long ? giant2.get() : dst, xi.data(),
+                                                    pi.data(), pi2.data(), xi.size(), pi2.size(), B * 2, L, st));
+                    fold(dst, ga);
+                    fold(giant2.get(), *gb);
+                    k += 2;
+                    continue;
+                }
+                xi.assign(ga.baby.begin(), ga.baby.end());
+                pi.assign(ga.diag.begin(), ga.diag.end());
+                util::hip_check(moai_ct_pt_dot(dev, babies.get(), plain, dst, xi.data(), pi.data(), xi.size(), B * 2, L, st));
+                fold(dst, ga);
+                k += 1;
             }
             store(acc.get(), new_scale);
             context_.sync(); // staging buffers go out of scope

@@ -242,6 +242,29 @@ def test_ct_pt_dot_matches_multiply_plain_add_chain(moai, terms, bits):
         for t in range(1, terms):
             want = octx.add(want, octx.multiply_plain(x[xi[t], b], 2, L, p[pi[t]]), 2, L)
         assert (got[b] == want).all()
+    # two sums over the same operands in one pass (two giant steps of a transform): the second over the leading terms only
+    for t2 in sorted({1, max(1, terms // 2), terms}):
+        pi2 = rng.integers(0, n_pt, size=t2)
+        do2 = moai.DeviceBuffer(B * 2 * L * n)
+        ctx.ct_pt_dot2(dx, dp, do, do2, xi, pi, pi2, B * 2, L)
+        assert (do.to_numpy((B, 2, L, n)) == got).all()
+        got2 = do2.to_numpy((B, 2, L, n))
+        ctx.ct_pt_dot(dx, dp, do, xi[:t2], pi2, B * 2, L)
+        assert (got2 == do.to_numpy((B, 2, L, n))).all(), t2
+        for b in range(B):
+            want = octx.multiply_plain(x[xi[0], b], 2, L, p[pi2[0]])
+            for t in range(1, t2):
+                want = octx.add(want, octx.multiply_plain(x[xi[t], b], 2, L, p[pi2[t]]), 2, L)
+            assert (got2[b] == want).all(), (t2, b)
+    with pytest.raises(moai.MoaiError):
+        ctx.ct_pt_dot2(dx, dp, do, do, xi, pi, pi, B * 2, L)  # the two outputs must differ
+    # a single polynomial per operand takes the one-polynomial-per-thread kernel
+    one, one2, ref = moai.DeviceBuffer(L * n), moai.DeviceBuffer(L * n), moai.DeviceBuffer(L * n)
+    ctx.ct_pt_dot2(dx, dp, one, one2, xi, pi, pi[:1], 1, L)
+    ctx.ct_pt_dot(dx, dp, ref, xi, pi, 1, L)
+    assert (one.to_numpy() == ref.to_numpy()).all()
+    ctx.ct_pt_dot(dx, dp, ref, xi[:1], pi[:1], 1, L)
+    assert (one2.to_numpy() == ref.to_numpy()).all()
 
 
 @pytest.mark.parametrize("L", [5, 4, 2])

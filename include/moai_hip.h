@@ -163,6 +163,14 @@ int moai_ct_pt_dot(moai_ctx *ctx, const uint64_t *x, const uint64_t *p, uint64_t
 int moai_ct_pt_dot2(moai_ctx *ctx, const uint64_t *x, const uint64_t *p, uint64_t *out, uint64_t *out2,
                     const uint32_t *x_index, const uint32_t *p_index, const uint32_t *p_index2, size_t terms, size_t terms2,
                     size_t n_poly, size_t L, void *stream);
+/* out = sum over ALL r < rows of multiply_plain(x[r], p[r]) accumulated with add_inplace: one output column of
+ * ct_pt_matrix_mul_wo_pre_w_mask (include/source/matrix_mul/Ct_pt_matrix_mul.hpp:120-150, every weight a full plaintext),
+ * any number of rows in one call; with p2 / out2 (both or neither) a second column over the same ciphertexts in the same
+ * pass.  x: [rows][n_poly][L][N]; p, p2: [rows][L][N] in NTT form; out, out2: [n_poly][L][N].  The sum is split over
+ * workgroups and folded by a second small kernel (exact: every partial sum is a canonical residue).  Same residues as the
+ * reference's multiply-reduce-add sequence. */
+int moai_ct_pt_dot_rows(moai_ctx *ctx, const uint64_t *x, const uint64_t *p, const uint64_t *p2, uint64_t *out, uint64_t *out2,
+                        size_t rows, size_t n_poly, size_t L, void *stream);
 
 /*
  * Column-packed ciphertext x plaintext matrix product with scalar-encoded weights: the body of

@@ -5,6 +5,7 @@
 // (cited per entry point in include/moai_hip.h).  Every kernel streams rows of N coefficients with
 // 16-byte accesses, one RNS prime per block row (blockIdx.y = polynomial row), so the per-prime
 // constants are wave-uniform scalars.
+#include <algorithm>
 #include <mutex>
 
 #include "launch.h"
@@ -536,6 +537,105 @@ __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
     }
 }
 
+// out = sum over ALL r < rows of x[r] (.) p[r] (and the same with a second plaintext set): the column of a ciphertext x
+// plaintext matrix product whose weights are full plaintexts (include/source/matrix_mul/Ct_pt_matrix_mul.hpp:103-170), one
+// multiply_plain + add_inplace per row in the reference.  The output is a handful of rows, so the parallelism comes from the
+// sum: blockIdx.z takes a slice of the rows and leaves a canonical partial sum, ct_pt_rowsum_reduce adds the slices.
+struct RowSumArgs
+{
+    const uint64_t *x;  // [rows][n_poly][L][N]
+    const uint64_t *p;  // [rows][L][N]
+    const uint64_t *p2; // second plaintext set or null
+    uint64_t *part;     // [splits][1 or 2][n_poly][L][N]
+    uint64_t *out, *out2;
+    const PrimeConst *pc;
+    uint32_t rows, L, n2, n_poly, splits;
+};
+
+template <bool TWO>
+__global__ __launch_bounds__(256) void ct_pt_rowsum_kernel(RowSumArgs g)
+{
+    const uint32_t row = blockIdx.y; // poly * L + prime
+    const uint32_t prime = row % g.L;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.n2)
+    {
+        return;
+    }
+    const uint32_t r0 = (uint32_t)(((uint64_t)g.rows * blockIdx.z) / g.splits);
+    const uint32_t r1 = (uint32_t)(((uint64_t)g.rows * (blockIdx.z + 1)) / g.splits);
+    const size_t x_stride = (size_t)g.n_poly * g.L * g.n2, p_stride = (size_t)g.L * g.n2;
+    const ulonglong2 *__restrict__ xb = reinterpret_cast<const ulonglong2 *>(g.x) + (size_t)row * g.n2 + i;
+    const ulonglong2 *__restrict__ pb = reinterpret_cast<const ulonglong2 *>(g.p) + (size_t)prime * g.n2 + i;
+    const ulonglong2 *__restrict__ pb2 = TWO ? reinterpret_cast<const ulonglong2 *>(g.p2) + (size_t)prime * g.n2 + i : nullptr;
+    uint64_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, mo0 = 0, mi0 = 0, mo1 = 0, mi1 = 0;
+    uint32_t since_fold = 0;
+#pragma unroll 4
+    for (uint32_t r = r0; r < r1; ++r)
+    {
+        const ulonglong2 a = xb[(size_t)r * x_stride];
+        const ulonglong2 b = pb[(size_t)r * p_stride];
+        mac128(lo0, hi0, a.x, b.x);
+        mac128(lo1, hi1, a.y, b.y);
+        if (TWO)
+        {
+            const ulonglong2 b2 = pb2[(size_t)r * p_stride];
+            mac128(mo0, mi0, a.x, b2.x);
+            mac128(mo1, mi1, a.y, b2.y);
+        }
+        if (++since_fold == 32u) // 32 products below 2^122 fit 128 bits for primes of at most 61 bits
+        {
+            since_fold = 0;
+            lo0 = barrett128(lo0, hi0, q, cr0, cr1);
+            lo1 = barrett128(lo1, hi1, q, cr0, cr1);
+            hi0 = hi1 = 0;
+            if (TWO)
+            {
+                mo0 = barrett128(mo0, mi0, q, cr0, cr1);
+                mo1 = barrett128(mo1, mi1, q, cr0, cr1);
+                mi0 = mi1 = 0;
+            }
+        }
+    }
+    const size_t plane = (size_t)g.n_poly * g.L * g.n2;
+    ulonglong2 *pp = reinterpret_cast<ulonglong2 *>(g.part) + (size_t)blockIdx.z * (TWO ? 2 : 1) * plane + (size_t)row * g.n2 + i;
+    ulonglong2 v;
+    v.x = barrett128(lo0, hi0, q, cr0, cr1);
+    v.y = barrett128(lo1, hi1, q, cr0, cr1);
+    pp[0] = v;
+    if (TWO)
+    {
+        v.x = barrett128(mo0, mi0, q, cr0, cr1);
+        v.y = barrett128(mo1, mi1, q, cr0, cr1);
+        pp[plane] = v;
+    }
+}
+
+// blockIdx.z = which output (0 / 1)
+__global__ __launch_bounds__(256) void ct_pt_rowsum_reduce(RowSumArgs g)
+{
+    const uint32_t row = blockIdx.y;
+    const uint64_t q = g.pc[row % g.L].q;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.n2)
+    {
+        return;
+    }
+    const uint32_t sets = g.p2 ? 2u : 1u;
+    const size_t plane = (size_t)g.n_poly * g.L * g.n2;
+    const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(g.part) + (size_t)blockIdx.z * plane + (size_t)row * g.n2 + i;
+    ulonglong2 acc = pp[0];
+    for (uint32_t z = 1; z < g.splits; ++z)
+    {
+        const ulonglong2 v = pp[(size_t)z * sets * plane];
+        acc.x = csub(acc.x + v.x, q);
+        acc.y = csub(acc.y + v.y, q);
+    }
+    (reinterpret_cast<ulonglong2 *>(blockIdx.z ? g.out2 : g.out) + (size_t)row * g.n2)[i] = acc;
+}
+
 static inline dim3 row_grid(const moai_ctx *c, size_t rows, uint32_t per_thread_chunks = 1)
 {
     uint32_t n2 = (uint32_t)(c->n >> 1);
@@ -955,6 +1055,75 @@ extern "C" int moai_ct_pt_dot2(moai_ctx *c, const uint64_t *x, const uint64_t *p
         return set_error(MOAI_EINVAL, "null argument");
     }
     return ct_pt_dot_common(c, x, p, out, out2, x_index, p_index, p_index2, terms, terms2, n_poly, L, stream);
+}
+
+extern "C" int moai_ct_pt_dot_rows(moai_ctx *c, const uint64_t *x, const uint64_t *p, const uint64_t *p2, uint64_t *out, uint64_t *out2,
+                                   size_t rows, size_t n_poly, size_t L, void *stream)
+{
+    trace_op("ct_pt_dot", L, n_poly * rows * (p2 ? 2 : 1)); // the products of moai_ct_pt_dot calls over the same rows
+    int rc = check_rows(c, n_poly, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (rows == 0 || rows > 0xffffffu)
+    {
+        return set_error(MOAI_EINVAL, "between 1 and 2^24 rows");
+    }
+    if (n_poly == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!x || !p || !out || (p2 != nullptr) != (out2 != nullptr) || out == out2)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    for (size_t r = 0; r < L; r++)
+    {
+        if (c->primes[r] >> 61)
+        {
+            return set_error(MOAI_ELOGIC, "lazy accumulation needs primes of at most 61 bits");
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t n2 = (uint32_t)(c->n >> 1);
+    const size_t blocks = (size_t)((n2 + 255) / 256) * n_poly * L;
+    size_t splits = (8192 + blocks - 1) / blocks; // enough workgroups to fill the chip several times over
+    splits = std::max<size_t>(1, std::min<size_t>({ splits, rows, 64 }));
+    const size_t sets = p2 ? 2 : 1;
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
+    void *wsp;
+    rc = workspace(c, splits * sets * n_poly * L * c->n * sizeof(uint64_t), s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    RowSumArgs g;
+    g.x = x;
+    g.p = p;
+    g.p2 = p2;
+    g.part = static_cast<uint64_t *>(wsp);
+    g.out = out;
+    g.out2 = out2;
+    g.pc = c->pc;
+    g.rows = (uint32_t)rows;
+    g.L = (uint32_t)L;
+    g.n2 = n2;
+    g.n_poly = (uint32_t)n_poly;
+    g.splits = (uint32_t)splits;
+    MOAI_CHECK_GRID_ROWS(n_poly * L);
+    const dim3 grid((n2 + 255) / 256, (uint32_t)(n_poly * L), (uint32_t)splits);
+    if (p2)
+    {
+        hipLaunchKernelGGL(ct_pt_rowsum_kernel<true>, grid, dim3(256), 0, s, g);
+    }
+    else
+    {
+        hipLaunchKernelGGL(ct_pt_rowsum_kernel<false>, grid, dim3(256), 0, s, g);
+    }
+    hipLaunchKernelGGL(ct_pt_rowsum_reduce, dim3((n2 + 255) / 256, (uint32_t)(n_poly * L), (uint32_t)sets), dim3(256), 0, s, g);
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
 }
 
 extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,

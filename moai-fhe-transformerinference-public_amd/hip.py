@@ -50,6 +50,7 @@ SYMBOLS = {
     "moai_ct_multiply_general": (C.c_int, [vp, vp, sz, vp, sz, vp, sz, sz, vp]),
     "moai_ct_dot": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_ct_pt_dot": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, vp]),
+    "moai_ct_pt_dot_rows": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "moai_ct_pt_dot2": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), sz, sz, sz, sz, vp]),
     "moai_ct_pt_matmul": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, sz, vp]),
     "moai_rescale": (C.c_int, [vp, vp, vp, sz, sz, sz, vp]),
@@ -262,6 +263,10 @@ class Context:
         pi2 = (C.c_uint32 * max(1, len(p_index2)))(*[int(v) for v in p_index2])
         _check(lib().moai_ct_pt_dot2(self.h, _ptr(x), _ptr(p), _ptr(out), _ptr(out2), xi, pi, pi2, len(x_index), len(p_index2), n_poly, L,
                                      stream))
+
+    def ct_pt_dot_rows(self, x, p, p2, out, out2, rows, n_poly, L, stream=None):
+        _check(lib().moai_ct_pt_dot_rows(self.h, _ptr(x), _ptr(p), _ptr(p2) if p2 is not None else None, _ptr(out),
+                                         _ptr(out2) if out2 is not None else None, rows, n_poly, L, stream))
 
     def ct_pt_matmul(self, x, w, out, rows, cols, size, L, stream=None):
         _check(lib().moai_ct_pt_matmul(self.h, _ptr(x), _ptr(w), _ptr(out), rows, cols, size, L, stream))

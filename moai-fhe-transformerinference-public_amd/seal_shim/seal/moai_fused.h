@@ -222,47 +222,41 @@ namespace moai_fused
         moai_ctx *dev = seal_context.device();
         const std::size_t ct_words = 2 * L * n;
         static_assert(sizeof(int) == 4, "bias_vec is uploaded as int32");
-        util::DeviceArray dmask((slots + 1) / 2, st), dconst(rows + rows, st); // constants, then max |coeff| per vector
+        // two columns per round: their 2 * rows plaintexts come from one moai_ckks_encode_masked call, and one pass over the
+        // input ciphertexts (moai_ct_pt_dot_rows) forms both columns' sums
+        const std::size_t group = cols >= 2 ? 2 : 1;
+        util::DeviceArray dmask((slots + 1) / 2, st), dconst(2 * group * rows, st); // constants, then max |coeff| per vector
         util::hip_check(moai_memcpy_h2d(dmask.get(), bias_vec.data(), slots * 4, st));
-        util::DeviceArray dX(rows * ct_words, st), dP(rows * L * n, st), dacc(cols * ct_words, st), dtmp(ct_words, st);
+        util::DeviceArray dX(rows * ct_words, st), dP(group * rows * L * n, st), dacc(cols * ct_words, st);
         for (std::size_t j = 0; j < rows; j++)
         {
             util::hip_check(moai_memcpy_d2d(dX.get() + j * ct_words, enc_X[j].device_data(), ct_words * 8, st));
         }
-        std::vector<double> wcol(rows), mx(rows);
-        std::vector<std::uint32_t> idx(64);
+        std::vector<double> wcol(group * rows), mx(group * rows);
         const int total_bits = cd->total_coeff_modulus_bit_count();
-        for (std::size_t c = 0; c < cols; c++)
+        for (std::size_t c = 0; c < cols; c += group)
         {
-            for (std::size_t j = 0; j < rows; j++)
+            const std::size_t g = std::min(group, cols - c);
+            for (std::size_t k = 0; k < g; k++)
             {
-                wcol[j] = W[j][c];
+                for (std::size_t j = 0; j < rows; j++)
+                {
+                    wcol[k * rows + j] = W[j][c + k];
+                }
             }
-            util::hip_check(moai_memcpy_h2d(dconst.get(), wcol.data(), rows * 8, st));
-            double *max_dev = reinterpret_cast<double *>(dconst.get() + rows);
+            util::hip_check(moai_memcpy_h2d(dconst.get(), wcol.data(), g * rows * 8, st));
+            double *max_dev = reinterpret_cast<double *>(dconst.get() + group * rows);
             util::hip_check(moai_ckks_encode_masked(dev, reinterpret_cast<const double *>(dconst.get()),
-                                                    reinterpret_cast<const std::int32_t *>(dmask.get()), slots, rows, dP.get(), L,
+                                                    reinterpret_cast<const std::int32_t *>(dmask.get()), slots, g * rows, dP.get(), L,
                                                     nullptr, scale, max_dev, st));
             std::uint64_t *acc = dacc.get() + c * ct_words;
-            for (std::size_t j0 = 0; j0 < rows; j0 += 64)
+            util::hip_check(moai_ct_pt_dot_rows(dev, dX.get(), dP.get(), g == 2 ? dP.get() + rows * L * n : nullptr, acc,
+                                                g == 2 ? acc + ct_words : nullptr, rows, 2, L, st));
+            util::hip_check(moai_memcpy_d2h(mx.data(), max_dev, g * rows * 8, st));
+            seal_context.sync(); // wcol / mx are reused by the next round
+            for (std::size_t k = 0; k < g * rows; k++)
             {
-                const std::size_t cnt = std::min<std::size_t>(64, rows - j0);
-                for (std::size_t t = 0; t < cnt; t++)
-                {
-                    idx[t] = static_cast<std::uint32_t>(j0 + t);
-                }
-                std::uint64_t *dst = j0 == 0 ? acc : dtmp.get();
-                util::hip_check(moai_ct_pt_dot(dev, dX.get(), dP.get(), dst, idx.data(), idx.data(), cnt, 2, L, st));
-                if (j0)
-                {
-                    util::hip_check(moai_add(dev, acc, dtmp.get(), acc, 2, L, st));
-                }
-            }
-            util::hip_check(moai_memcpy_d2h(mx.data(), max_dev, rows * 8, st));
-            seal_context.sync(); // wcol / mx are reused by the next column
-            for (double m : mx)
-            {
-                int bits = static_cast<int>(std::ceil(std::log2(std::max<>(m, 1.0)))) + 1;
+                int bits = static_cast<int>(std::ceil(std::log2(std::max<>(mx[k], 1.0)))) + 1;
                 if (!(bits < total_bits))
                 {
                     throw std::invalid_argument("encoded values are too large");

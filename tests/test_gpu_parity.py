@@ -267,6 +267,47 @@ def test_ct_pt_dot_matches_multiply_plain_add_chain(moai, terms, bits):
     assert (one2.to_numpy() == ref.to_numpy()).all()
 
 
+@pytest.mark.parametrize("rows,bits,logn", [(1, [51, 46], 10), (70, [61, 60, 40], 10), (333, [61, 61], 11), (3072, [51, 46], 10)])
+def test_ct_pt_dot_rows_matches_multiply_plain_add_chain(moai, rows, bits, logn):
+    """one column of the masked ciphertext x plaintext product (Ct_pt_matrix_mul.hpp:120-150): sum over all rows of
+    multiply_plain(x[r], p[r]), and two columns in one pass; all-(q-1) residues in the first coefficients push the lazy
+    accumulators to their bound; 3072 rows is the final feed-forward product's count"""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    L = len(primes)
+    rng = np.random.default_rng(rows)
+    x = O.uniform_rns(rng, primes, (rows, 2), n)
+    p = O.uniform_rns(rng, primes, (rows,), n)
+    p2 = O.uniform_rns(rng, primes, (rows,), n)
+    for r, q in enumerate(primes):
+        x[:, :, r, :8] = q - 1
+        p[:, r, :8] = q - 1
+    def column(pl):
+        acc = np.zeros((2, L, n), dtype=object)
+        xo, po = x.astype(object), pl.astype(object)
+        for r in range(L):
+            acc[:, r] = (xo[:, :, r] * po[:, None, r]).sum(axis=0) % primes[r]
+        return acc.astype(np.uint64)
+    want, want2 = column(p), column(p2)
+    if rows <= 70:  # and the oracle's own call chain on the small cases
+        ref = octx.multiply_plain(x[0], 2, L, p[0])
+        for r in range(1, rows):
+            ref = octx.add(ref, octx.multiply_plain(x[r], 2, L, p[r]), 2, L)
+        assert (ref.reshape(2, L, n) == want).all()
+    dx, dp, dp2 = up(moai, x), up(moai, p), up(moai, p2)
+    o1, o2 = moai.DeviceBuffer(2 * L * n), moai.DeviceBuffer(2 * L * n)
+    ctx.ct_pt_dot_rows(dx, dp, None, o1, None, rows, 2, L)
+    assert (o1.to_numpy((2, L, n)) == want).all()
+    ctx.ct_pt_dot_rows(dx, dp2, dp, o2, o1, rows, 2, L)
+    assert (o2.to_numpy((2, L, n)) == want2).all()
+    assert (o1.to_numpy((2, L, n)) == want).all()
+    with pytest.raises(moai.MoaiError):
+        ctx.ct_pt_dot_rows(dx, dp, dp2, o1, None, rows, 2, L)
+    with pytest.raises(moai.MoaiError):
+        ctx.ct_pt_dot_rows(dx, dp, None, o1, None, 0, 2, L)
+
+
 @pytest.mark.parametrize("L", [5, 4, 2])
 def test_rescale_and_drop(moai, env12, L, ks_arith):
     logn, primes, octx, ctx = env12

@@ -151,6 +151,143 @@ __global__ __launch_bounds__(256) void ckks_fft_contig(EncArgs g)
     }
 }
 
+// The same twelve stages for n >= 4096 with sixteen elements per thread: four stages at a time in registers (the element
+// index bits 0-3, then 4-7, then 8-11 vary inside a thread), two exchanges through one 32 KiB LDS buffer (real parts, then
+// imaginary parts).  Every butterfly is the same gs_cbfly on the same operands as in ckks_fft_contig -- only which thread
+// performs it changes -- so the results are the same bits.  LDS slot of element e: e ^ ((e >> 4) & 15) (at most two-way bank
+// conflicts in every access pattern below).
+__device__ __forceinline__ uint32_t enc_slot(uint32_t e)
+{
+    return e ^ ((e >> 4) & 15u);
+}
+
+// stages S0..S0+3 on the sixteen elements of a thread; element k of the thread is tile element e0 + k * estep
+template <int S0>
+__device__ __forceinline__ void enc_round(double (&re)[16], double (&im)[16], const EncArgs &g, uint32_t n, uint32_t base, uint32_t e0,
+                                          uint32_t estep)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+    {
+        const uint32_t st = S0 + s;
+        const uint32_t m = n >> (st + 1);
+        const double2 *roots = g.roots + (n - 2 * m + 1) + (base >> (st + 1));
+        const bool last = (st + 1 == g.logn);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            if (k & (1 << s))
+            {
+                continue;
+            }
+            const uint32_t x = e0 + (uint32_t)k * estep; // the pair's lower element inside the tile
+            const double2 r = roots[x >> (st + 1)];
+            if (last)
+            {
+                gs_cbfly_last(re[k], im[k], re[k + (1 << s)], im[k + (1 << s)], r.x, r.y, g.fix);
+            }
+            else
+            {
+                gs_cbfly(re[k], im[k], re[k + (1 << s)], im[k + (1 << s)], r.x, r.y);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ckks_fft_contig16(EncArgs g)
+{
+    __shared__ double buf[ENC_TILE];
+    const uint32_t n = 1u << g.logn;
+    const uint32_t slots = n >> 1;
+    const uint32_t tiles = n >> ENC_TILE_LOG;
+    const uint32_t b = blockIdx.x / tiles;
+    const uint32_t base = (blockIdx.x % tiles) << ENC_TILE_LOG;
+    const uint32_t tid = threadIdx.x;
+    double re[16], im[16];
+
+    // gather (ckks.h:505-510 through the inverse map), elements 16 tid .. 16 tid + 15
+    const double *vals = g.mask ? g.values + b : g.values + (size_t)b * g.values_size * (g.is_complex ? 2 : 1);
+    const uint4 *sm = reinterpret_cast<const uint4 *>(g.src_map + base + 16 * tid);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++)
+    {
+        const uint4 s4 = sm[k4];
+        const uint32_t ss[4] = { s4.x, s4.y, s4.z, s4.w };
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const uint32_t s = ss[u];
+            const uint32_t slot = s & (slots - 1);
+            double r = 0.0, i = 0.0;
+            if (g.mask)
+            {
+                if (slot < g.values_size)
+                {
+                    r = g.mask[slot] == 1 ? vals[0] : 0.0;
+                    i = s >= slots ? -0.0 : 0.0;
+                }
+            }
+            else if (slot < g.values_size)
+            {
+                r = g.is_complex ? vals[2 * slot] : vals[slot];
+                i = g.is_complex ? vals[2 * slot + 1] : 0.0;
+                if (s >= slots)
+                {
+                    i = -i;
+                }
+            }
+            re[4 * k4 + u] = r;
+            im[4 * k4 + u] = i;
+        }
+    }
+    enc_round<0>(re, im, g, n, base, 16 * tid, 1);
+    // exchange 1: element 16 tid + k  ->  thread (hi4, lo4) = (bits 8-11, bits 0-3) holds hi4 * 256 + k * 16 + lo4
+    const uint32_t hi4 = tid >> 4, lo4 = tid & 15u;
+#pragma unroll
+    for (int part = 0; part < 2; part++)
+    {
+        double(&v)[16] = part ? im : re;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            buf[enc_slot(16 * tid + k)] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            v[k] = buf[enc_slot(hi4 * 256 + k * 16 + lo4)];
+        }
+        __syncthreads();
+    }
+    enc_round<4>(re, im, g, n, base, hi4 * 256 + lo4, 16);
+    // exchange 2: ->  thread tid holds k * 256 + tid
+#pragma unroll
+    for (int part = 0; part < 2; part++)
+    {
+        double(&v)[16] = part ? im : re;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            buf[enc_slot(hi4 * 256 + k * 16 + lo4)] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            v[k] = buf[enc_slot(k * 256 + tid)];
+        }
+        __syncthreads();
+    }
+    enc_round<8>(re, im, g, n, base, tid, 256);
+    double2 *out = g.scratch + (size_t)b * n + base;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        out[k * 256 + tid] = make_double2(re[k], im[k]);
+    }
+}
+
 // |c| of an integer-valued double as mant * 2^sh with mant < 2^53 (sh < 0 only shifts out zero bits)
 __device__ __forceinline__ void split_rounded(double c, uint64_t &mag, int &sh)
 {
@@ -558,7 +695,14 @@ static int encode_impl(moai_ctx *c, const double *values, const int32_t *mask, i
 
     const uint32_t tile = c->n < ENC_TILE ? (uint32_t)c->n : ENC_TILE;
     const uint32_t tiles = (uint32_t)(c->n / tile);
-    hipLaunchKernelGGL(ckks_fft_contig, dim3((uint32_t)(n_batch * tiles)), dim3(256), 0, s, g);
+    if (c->logn >= ENC_TILE_LOG)
+    {
+        hipLaunchKernelGGL(ckks_fft_contig16, dim3((uint32_t)(n_batch * tiles)), dim3(256), 0, s, g);
+    }
+    else
+    {
+        hipLaunchKernelGGL(ckks_fft_contig, dim3((uint32_t)(n_batch * tiles)), dim3(256), 0, s, g);
+    }
     MOAI_LAUNCH_CHECK();
     const int R = c->logn > ENC_TILE_LOG ? c->logn - ENC_TILE_LOG : 0;
     dim3 grid((tile + 255) / 256, (uint32_t)((L + ENC_ROWS_PER_BLOCK - 1) / ENC_ROWS_PER_BLOCK), (uint32_t)n_batch);

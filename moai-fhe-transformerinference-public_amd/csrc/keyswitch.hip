@@ -1074,8 +1074,8 @@ static void hoist_contig_finish(moai_ctx *c, uint64_t *tmp, size_t L, size_t bat
 
 template <int LOGN>
 static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *in, size_t L, size_t batch, const KsGroup &grp,
-                       size_t G, int mode, const uint32_t *const *tables, const uint64_t *const *keys, const uint64_t *const *corrs,
-                       uint64_t *acc, size_t acc_stride_words, size_t R, hipStream_t s)
+                       size_t G, int mode, const uint32_t *const *tables, const uint32_t *const *itables, const uint64_t *const *keys,
+                       const uint64_t *const *corrs, uint64_t *acc, size_t acc_stride_words, size_t R, hipStream_t s)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     KsP1Args p1;
@@ -1097,8 +1097,51 @@ static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint
     MOAI_LAUNCH_CHECK();
     hoist_contig_finish<LOGN>(c, tmp, L, batch, grp, G, mode, s);
     MOAI_LAUNCH_CHECK();
+    // FP64 modes: four or two rotations per pass over the digits (ks_hoisted_mac2); MOAI_KS_HOIST_PAIR=0 keeps one per pass,
+    // 2 at most two
+    const long pair = (mode == M_FPN || mode == M_FPR) ? tuning("MOAI_KS_HOIST_PAIR", 4) : 0;
     for (size_t r = 0; r < R; ++r)
     {
+        const size_t nr = pair >= 4 && r + 3 < R ? 4 : (pair >= 1 && r + 1 < R ? 2 : 1);
+        if (nr > 1)
+        {
+            HoistMac2Args m2;
+            m2.dig = tmp;
+            m2.ct = in;
+            for (size_t h = 0; h < 4; ++h)
+            {
+                const size_t rr = r + (h < nr ? h : 0);
+                m2.itable[h] = itables[rr];
+                m2.key[h] = keys[rr];
+                m2.corr[h] = corrs[rr];
+                m2.acc[h] = acc + rr * acc_stride_words;
+            }
+            m2.pc = c->pc;
+            m2.grp = grp;
+            m2.L = (uint32_t)L;
+            m2.G = (uint32_t)G;
+            m2.k = (uint32_t)c->k;
+            m2.B = (uint32_t)batch;
+            m2.total_work = (uint32_t)(batch * G * TPR * 2);
+            if (mode == M_FPN && nr == 4)
+            {
+                hipLaunchKernelGGL((ks_hoisted_mac2<LOGN, false, 4>), dim3(m2.total_work), dim3(256), 0, s, m2);
+            }
+            else if (mode == M_FPN)
+            {
+                hipLaunchKernelGGL((ks_hoisted_mac2<LOGN, false, 2>), dim3(m2.total_work), dim3(256), 0, s, m2);
+            }
+            else if (nr == 4)
+            {
+                hipLaunchKernelGGL((ks_hoisted_mac2<LOGN, true, 4>), dim3(m2.total_work), dim3(256), 0, s, m2);
+            }
+            else
+            {
+                hipLaunchKernelGGL((ks_hoisted_mac2<LOGN, true, 2>), dim3(m2.total_work), dim3(256), 0, s, m2);
+            }
+            r += nr - 1;
+            continue;
+        }
         HoistMacArgs m;
         m.dig = tmp;
         m.ct = in;
@@ -1233,7 +1276,7 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
         return set_error(MOAI_EINVAL, "at most 64 rotations per call");
     }
     hipStream_t s = (hipStream_t)stream;
-    std::vector<const uint32_t *> tables(R);
+    std::vector<const uint32_t *> tables(R), itables(R);
     for (size_t r = 0; r < R; ++r)
     {
         if (!galois_keys[r] || !corrections[r] || !outs[r] || outs[r] == in)
@@ -1241,6 +1284,18 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
             return set_error(MOAI_EINVAL, "null key, correction or output (an output must not be the input)");
         }
         rc = galois_table(c, galois_elts[r], s, &tables[r]);
+        if (rc)
+        {
+            return rc;
+        }
+        // the inverse permutation is the table of the inverse element (mod 2N, by Newton's iteration on an odd number)
+        const uint32_t two_n_mask = (uint32_t)(2 * n - 1);
+        uint32_t inv = galois_elts[r];
+        for (int it = 0; it < 5; ++it)
+        {
+            inv = (inv * (2u - galois_elts[r] * inv)) & two_n_mask;
+        }
+        rc = galois_table(c, inv, s, &itables[r]);
         if (rc)
         {
             return rc;
@@ -1333,11 +1388,11 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
                 }
                 switch (c->logn)
                 {
-                case 12: rc = hoist_group<12>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                case 13: rc = hoist_group<13>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                case 14: rc = hoist_group<14>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                case 15: rc = hoist_group<15>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                default: rc = hoist_group<16>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 12: rc = hoist_group<12>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 13: rc = hoist_group<13>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 14: rc = hoist_group<14>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 15: rc = hoist_group<15>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                default: rc = hoist_group<16>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
                 }
                 if (rc)
                 {

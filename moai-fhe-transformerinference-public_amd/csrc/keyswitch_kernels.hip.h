@@ -603,6 +603,103 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac(HoistMacArgs a)
     }
 }
 
+// The same sums for NR = 2 or 4 rotations in one pass over the digits (FP64 arithmetic only): a workgroup walks 2048 INPUT
+// positions, every digit value is loaded once and multiplied into every rotation's keys at the positions it is sent to
+// (itable = the inverse permutation: itable[pos] is where position pos lands), and the sums are stored at those positions.
+// Each output still adds its J terms in the order J = 0 .. L-1 with the same operations as ks_hoisted_mac: the same bits.
+struct HoistMac2Args
+{
+    const uint64_t *dig;
+    const uint64_t *ct;
+    const uint32_t *itable[4];
+    const uint64_t *key[4];
+    const uint64_t *corr[4];
+    uint64_t *acc[4];
+    const PrimeConst *pc;
+    KsGroup grp;
+    uint32_t L, G, k, B;
+    uint32_t total_work;
+};
+
+template <int LOGN, bool FPR, int NR>
+__global__ __launch_bounds__(256, 4) void ks_hoisted_mac2(HoistMac2Args a)
+{
+    constexpr uint32_t TPR8 = 1u << (LOGN - 11);
+    constexpr int E = 8 / NR; // positions per thread and pass: NR * E accumulator pairs, NR passes of 256 * E positions cover the tile
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
+    const uint32_t bq = w % a.B;
+    w /= a.B;
+    const uint32_t tile = w % TPR8;
+    const uint32_t g = w / TPR8;
+    const uint32_t prime = a.grp.prime[g];
+    const uint32_t slot = a.grp.slot[g];
+    const PrimeConst *pc = a.pc + prime;
+    const uint64_t q = pc->q;
+    const double qd = u2d(pc->qd), qinv = u2d(pc->qinv);
+    for (uint32_t pass = 0; pass < (uint32_t)NR; ++pass)
+    {
+        const uint32_t pbase = (tile << 11) + pass * (256u * E) + threadIdx.x;
+        uint32_t dst[NR][E];
+        double s0[NR][E], s1[NR][E];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+        {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+            {
+                dst[r][e] = a.itable[r][pbase + ((uint32_t)e << 8)];
+                s0[r][e] = 0.0;
+                s1[r][e] = 0.0;
+            }
+        }
+        for (uint32_t J = 0; J < a.L; ++J)
+        {
+            const uint64_t *__restrict__ row = (slot == J) ? a.ct + (((size_t)(bq * 2 + 1) * a.L + J) << LOGN)
+                                                           : a.dig + ((((size_t)bq * a.G + g) * a.L + J) << LOGN);
+            double v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+            {
+                v[e] = fp_red(fp_from_u52(row[pbase + ((uint32_t)e << 8)]), qd, qinv);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+            {
+                const uint64_t *__restrict__ k0 = a.key[r] + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN);
+                const uint64_t *__restrict__ k1 = a.key[r] + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                {
+                    double t0 = s0[r][e] + fp_mulmod_q(v[e], fp_from_u52(k0[dst[r][e]]), qd, qinv);
+                    double t1 = s1[r][e] + fp_mulmod_q(v[e], fp_from_u52(k1[dst[r][e]]), qd, qinv);
+                    if (FPR || (J & 15u) == 15u)
+                    {
+                        t0 = fp_red(t0, qd, qinv);
+                        t1 = fp_red(t1, qd, qinv);
+                    }
+                    s0[r][e] = t0;
+                    s1[r][e] = t1;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+        {
+            uint64_t *__restrict__ o0 = a.acc[r] + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN);
+            uint64_t *__restrict__ o1 = a.acc[r] + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN);
+            const uint64_t *__restrict__ c0 = a.corr[r] + (((size_t)0 * (a.L + 1) + slot) << LOGN);
+            const uint64_t *__restrict__ c1 = a.corr[r] + (((size_t)1 * (a.L + 1) + slot) << LOGN);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+            {
+                const uint32_t d = dst[r][e];
+                o0[d] = csub(fp_to_canonical(s0[r][e], qd, qinv) + c0[d], q);
+                o1[d] = csub(fp_to_canonical(s1[r][e], qd, qinv) + c1[d], q);
+            }
+        }
+    }
+}
+
 // ---- "divide by the last modulus and round" with its element-wise halves fused into the NTT ---------
 // (RNSTool::divide_and_round_q_last_ntt_inplace SEAL/util/rns.cpp:830-901; key-switch mod-down
 // SEAL/evaluator.cpp:2913-3018).  `last` [P][N] is the dropped row in coefficient form.

@@ -854,6 +854,14 @@ def test_hoisted_rotations_equal_separate_rotations(moai, logn, bits, L, B, ks_a
         for b in range(B):
             assert (got[r, b] == octx.apply_galois(ct[b], L, e, kk).reshape(2, L, n)).all(), (r, b)
     assert (dct.to_numpy(ct.shape) == ct).all()  # the input is left alone
+    # the FP64 modes take four (or two) rotations per pass over the digits; two at most, and one per pass: the same bits
+    try:
+        for per_pass in (2, 0):
+            moai.hip.set_tuning("MOAI_KS_HOIST_PAIR", per_pass)
+            assert not ctx.apply_galois_hoisted(dct, dout, L, elts, dkeys, corrs, B)
+            assert (dout.to_numpy((len(steps), B, 2, L, n)) == got).all(), per_pass
+    finally:
+        moai.hip.set_tuning("MOAI_KS_HOIST_PAIR", 4)
     # a transparent-looking input: c1 = NTT(polynomial with zero coefficients) -> the identity does not hold -> fallback
     ct0 = ct.copy()
     sparse = np.zeros((1, L, n), dtype=np.uint64)

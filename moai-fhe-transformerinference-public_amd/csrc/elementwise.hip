@@ -228,10 +228,12 @@ __global__ __launch_bounds__(256) void drop_rows_kernel(const uint64_t *in, uint
 }
 
 // out[row][i] = in[row][table[i]]   (apply_galois_ntt, SEAL/util/galois.cpp:192-218)
+// source row of output row r: (r / L) * src_poly_rows + r % L -- src_poly_rows = L for a dense copy, 2 L to take the first
+// polynomial of every size-2 ciphertext only
 __global__ __launch_bounds__(256) void galois_gather_kernel(const uint64_t *in, uint64_t *out, const uint32_t *table,
-                                                            uint32_t n)
+                                                            uint32_t n, uint32_t L, uint32_t src_poly_rows)
 {
-    const uint64_t *s = in + (size_t)blockIdx.y * n;
+    const uint64_t *s = in + ((size_t)(blockIdx.y / L) * src_poly_rows + blockIdx.y % L) * n;
     uint64_t *d = out + (size_t)blockIdx.y * n;
     for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 2u; i < n; i += gridDim.x * 512u)
     {
@@ -1189,10 +1191,32 @@ extern "C" int moai_galois_permute(moai_ctx *c, const uint64_t *in, uint64_t *ou
     }
     uint32_t bx = (uint32_t)((c->n + 511) / 512);
     hipLaunchKernelGGL(galois_gather_kernel, dim3(bx, (uint32_t)(n_poly * L)), dim3(256), 0, (hipStream_t)stream, in,
-                       out, table, (uint32_t)c->n);
+                       out, table, (uint32_t)c->n, (uint32_t)L, (uint32_t)L);
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
 }
+
+namespace moai {
+// out [batch][L][N] = the Galois permutation of polynomial 0 of every ciphertext of in [batch][2][L][N]
+int galois_permute_c0(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t batch, size_t L, uint32_t galois_elt, hipStream_t s)
+{
+    const uint32_t *table;
+    int rc = galois_table(c, galois_elt, s, &table);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch * L == 0)
+    {
+        return MOAI_OK;
+    }
+    MOAI_CHECK_GRID_ROWS(batch * L);
+    hipLaunchKernelGGL(galois_gather_kernel, dim3((uint32_t)((c->n + 511) / 512), (uint32_t)(batch * L)), dim3(256), 0, s, in, out, table,
+                       (uint32_t)c->n, (uint32_t)L, (uint32_t)(2 * L));
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+} // namespace moai
 
 extern "C" uint32_t moai_galois_elt_from_step(const moai_ctx *c, int step)
 {

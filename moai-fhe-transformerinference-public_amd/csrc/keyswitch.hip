@@ -1312,7 +1312,7 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
         const size_t sz_acc = align256(R * acc_stride_words * sizeof(uint64_t));
         const size_t sz_last = align256(batch * 2 * row_bytes);
         const size_t sz_u = align256(2 * batch * L * row_bytes);
-        const size_t sz_c0 = align256(batch * 2 * L * row_bytes);
+        const size_t sz_c0 = align256(batch * L * row_bytes);
         std::unique_lock<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
         void *wsp;
         rc = workspace(c, 256 + sz_t + sz_tmp + sz_acc + sz_last + sz_u + sz_c0, s, &wsp);
@@ -1404,8 +1404,8 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
             for (size_t r = 0; r < R; ++r)
             {
                 uint64_t *acc_r = acc + r * acc_stride_words;
-                // pc0 [B][2][L][N] = perm(in): polynomial 0 is the addend, polynomial 1 is not read (add_mode 2)
-                rc = moai_galois_permute(c, in, pc0, batch * 2, L, galois_elts[r], stream);
+                // pc0 [B][L][N] = perm(c0 of in): the addend of the even polynomials (add_mode 2, ciphertexts L rows apart)
+                rc = galois_permute_c0(c, in, pc0, batch, L, galois_elts[r], s);
                 if (rc)
                 {
                     return rc;
@@ -1414,7 +1414,7 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
                 hipLaunchKernelGGL(sum_rows_kernel, rgrid(c, batch * 2), dim3(256), 0, s, acc_r, last, (uint32_t)(L + 1), (uint32_t)L, 1u,
                                    (size_t)0, c->pc, (uint32_t)(k - 1), n2);
                 MOAI_LAUNCH_CHECK();
-                rc = moddown(c, last, acc_r, (uint32_t)(L + 1), u, outs[r], batch * 2, L, (uint32_t)(k - 1), pc0, (uint32_t)(2 * L), 2, s);
+                rc = moddown(c, last, acc_r, (uint32_t)(L + 1), u, outs[r], batch * 2, L, (uint32_t)(k - 1), pc0, (uint32_t)L, 2, s);
                 if (rc)
                 {
                     return rc;

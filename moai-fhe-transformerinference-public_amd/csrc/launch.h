@@ -24,5 +24,7 @@ int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out);
 int reserve_for_stream(moai_ctx *c, void *stream, size_t bytes, void **out, bool headroom);
 // device pointer to the Galois permutation table of `elt` (built on first use)
 int galois_table(moai_ctx *c, uint32_t elt, hipStream_t s, const uint32_t **out);
+// out [batch][L][N] = the Galois permutation of polynomial 0 of every ciphertext of in [batch][2][L][N]
+int galois_permute_c0(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t batch, size_t L, uint32_t galois_elt, hipStream_t s);
 
 } // namespace moai

@@ -21,6 +21,9 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <chrono>
 #include <array>
 #include <cmath>
 #include <complex>
@@ -282,7 +285,12 @@ namespace seal
                     *granted = bytes;
                 }
                 void *p = nullptr;
+                const auto t_malloc = std::chrono::steady_clock::now();
                 int rc = moai_malloc(&p, bytes);
+                fresh_count_.fetch_add(1, std::memory_order_relaxed);
+                fresh_us_.fetch_add(static_cast<std::uint64_t>(
+                                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_malloc).count()),
+                                    std::memory_order_relaxed);
                 if (rc != MOAI_OK)
                 {
                     // Out of device memory: ONE thread gives cached blocks back -- the least recently released first (the
@@ -321,16 +329,21 @@ namespace seal
                 }
                 moai_free(p);
             }
-            // gives cached blocks back to the device, least recently released first, until `at_least` bytes are returned
-            // (everything by default); returns the bytes freed
+            // gives cached blocks back to the device until `at_least` bytes are returned (everything by default): the blocks below
+            // 256 MiB first, least recently released first among them, then the large ones in the same order.  Getting a
+            // large block from the device again costs tens of milliseconds (measured: 40 ms per GiB), a small one next to
+            // nothing, and the large blocks are the packed ciphertexts that the next bootstrapping round wants back.
+            // Returns the bytes freed.
             std::size_t trim(std::size_t at_least = ~std::size_t(0))
             {
+                constexpr std::size_t large = std::size_t(256) << 20;
                 std::vector<void *> victims;
                 std::size_t freed = 0;
                 {
                     std::lock_guard<std::mutex> g(mu_);
                     struct Age
                     {
+                        int cls;
                         std::uint64_t tick;
                         std::size_t bytes;
                     };
@@ -339,11 +352,11 @@ namespace seal
                     {
                         for (auto &blk : kv.second)
                         {
-                            ages.push_back({ blk.tick, kv.first.second });
+                            ages.push_back({ kv.first.second >= large ? 1 : 0, blk.tick, kv.first.second });
                         }
                     }
-                    std::sort(ages.begin(), ages.end(), [](const Age &a, const Age &b) { return a.tick < b.tick; });
-                    std::uint64_t newest_victim = 0;
+                    std::sort(ages.begin(), ages.end(), [](const Age &a, const Age &b) { return a.cls != b.cls ? a.cls < b.cls : a.tick < b.tick; });
+                    std::uint64_t newest_victim[2] = { 0, 0 };
                     for (auto &a : ages)
                     {
                         if (freed >= at_least)
@@ -351,13 +364,14 @@ namespace seal
                             break;
                         }
                         freed += a.bytes;
-                        newest_victim = a.tick;
+                        newest_victim[a.cls] = a.tick;
                     }
                     for (auto it = free_.begin(); it != free_.end();)
                     {
-                        auto &list = it->second; // ticks ascend within a list: the victims are a prefix
+                        auto &list = it->second; // one size, so one class; ticks ascend within a list: the victims are a prefix
+                        const std::uint64_t cut = newest_victim[it->first.second >= large ? 1 : 0];
                         std::size_t k = 0;
-                        while (k < list.size() && list[k].tick <= newest_victim && freed)
+                        while (k < list.size() && list[k].tick <= cut)
                         {
                             victims.push_back(list[k].ptr);
                             k++;
@@ -367,9 +381,16 @@ namespace seal
                     }
                     cached_ -= freed;
                 }
+                const auto t0 = std::chrono::steady_clock::now();
                 for (void *p : victims)
                 {
                     moai_free(p);
+                }
+                if (std::getenv("MOAI_POOL_DEBUG"))
+                {
+                    std::fprintf(stderr, "[pool] gave back %zu blocks, %.1f GiB (asked for %.1f) in %.0f ms; %.1f GiB stay cached\n", victims.size(),
+                                 freed / 1073741824.0, (at_least == ~std::size_t(0) ? 0.0 : at_least / 1073741824.0),
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), cached_bytes() / 1073741824.0);
                 }
                 return freed;
             }
@@ -377,6 +398,11 @@ namespace seal
             {
                 std::lock_guard<std::mutex> g(mu_);
                 return cached_;
+            }
+            // requests that went to the device allocator instead of the cache, and the time spent there (diagnostics)
+            std::pair<std::uint64_t, double> fresh_allocations() const
+            {
+                return { fresh_count_.load(), fresh_us_.load() * 1e-3 };
             }
             // cached blocks are deliberately not returned at static destruction: the HIP runtime may already be
             // gone by then, and the process is exiting anyway
@@ -397,6 +423,7 @@ namespace seal
             std::map<std::pair<void *, std::size_t>, std::vector<Block>> free_;
             std::size_t cached_ = 0, cap_ = 0;
             std::uint64_t clock_ = 0;
+            std::atomic<std::uint64_t> fresh_count_{ 0 }, fresh_us_{ 0 };
         };
 
         // RAII device buffer of uint64 words

@@ -620,6 +620,18 @@ static void device_pool()
     pool.release(b2, g2, nullptr);
     CHECK(pool.trim(MB + 1) == 3 * MB); // whole blocks, oldest first, until at least that much is back
     CHECK(pool.trim() == 0);
+    // blocks of 256 MiB and more are the last to go, however old: they cost the most to get back from the device
+    const size_t big = size_t(256) << 20;
+    size_t gl = 0, gs = 0;
+    void *l = pool.acquire(big, nullptr, &gl), *sm = pool.acquire(MB, nullptr, &gs);
+    pool.release(l, gl, nullptr); // the older one
+    pool.release(sm, gs, nullptr);
+    CHECK(pool.trim(1) == MB);
+    CHECK(pool.cached_bytes() == big);
+    size_t g3 = 0;
+    CHECK(pool.acquire(big, nullptr, &g3) == l);
+    pool.release(l, g3, nullptr);
+    CHECK(pool.trim(1) == big);
 }
 
 int main()

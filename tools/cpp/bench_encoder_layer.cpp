@@ -119,8 +119,17 @@ int main(int argc, char **argv)
             {
                 while (context.get_context_data(c.parms_id())->chain_index() != 0) evaluator.mod_switch_to_next_inplace(c);
             }
+            const double t_pack = now_s();
+            const auto fresh0 = seal::util::DevicePool::instance().fresh_allocations();
             Ciphertext packed = moai_fused::pack(part, context), res;
             bootstrapper.bootstrap_full_3(res, packed);
+            if (getenv("MOAI_POOL_DEBUG"))
+            {
+                context.sync();
+                const auto fresh1 = seal::util::DevicePool::instance().fresh_allocations();
+                fprintf(stderr, "  [pack %d] %.2f s; %llu device allocations, %.0f ms in them\n", pk_i, now_s() - t_pack,
+                        (unsigned long long)(fresh1.first - fresh0.first), fresh1.second - fresh0.second);
+            }
             vector<Ciphertext> un;
             moai_fused::unpack(res, context, un);
             for (int b = 0; b < B; b++)

@@ -270,6 +270,7 @@ namespace seal
                         {
                             void *p = it->second.back().ptr; // the most recently released: the old ones age towards a trim
                             it->second.pop_back();
+                            last_hit_[it->first] = now_seconds();
                             cached_ -= it->first.second;
                             if (granted)
                             {
@@ -293,9 +294,8 @@ namespace seal
                                     std::memory_order_relaxed);
                 if (rc != MOAI_OK)
                 {
-                    // Out of device memory: ONE thread gives cached blocks back -- the least recently released first (the
-                    // sizes of a stage that is over, not the ones the running stage keeps reusing), a quarter of the cache
-                    // at a time, because every hipFree waits for the device; the other threads wait here and retry once
+                    // Out of device memory: ONE thread gives cached blocks back (trim() says which), a few GiB at a time: what
+                    // stays cached is what later stages find; the other threads wait here and retry once
                     // it is done (a thread that retried while the blocks were still being freed would fail for good:
                     // MOAI's OpenMP loops allocate from 16+ threads).
                     std::lock_guard<std::mutex> g(oom_mu_);
@@ -305,7 +305,7 @@ namespace seal
                         std::size_t want;
                         {
                             std::lock_guard<std::mutex> g2(mu_);
-                            want = std::max<std::size_t>({ 4 * bytes, cached_ / 4, std::size_t(8) << 30 });
+                            want = std::max<std::size_t>(2 * bytes, std::size_t(4) << 30);
                         }
                         if (trim(want) == 0)
                         {
@@ -318,25 +318,43 @@ namespace seal
             }
             void release(void *p, std::size_t bytes, void *stream)
             {
+                if (bytes > cap_)
+                {
+                    moai_free(p); // larger than the whole cache may be (MOAI_POOL_CACHE_MB=0 switches caching off)
+                    return;
+                }
+                bool full;
                 {
                     std::lock_guard<std::mutex> g(mu_);
-                    if (cached_ + bytes <= cap_)
-                    {
-                        free_[{ stream, bytes }].push_back({ p, ++clock_ });
-                        cached_ += bytes;
-                        return;
-                    }
+                    full = cached_ + bytes > cap_;
                 }
-                moai_free(p);
+                if (full)
+                {
+                    // The cache is at its cap.  The block coming in is the most recently used one there is: room is made by
+                    // trim()'s order instead (idle lists first), a couple of GiB at a time.  (Giving back the incoming block --
+                    // what this did before -- turned every release into a hipFree and every request into a hipMalloc for as
+                    // long as the cache stayed full: 55 000 device allocations in one attention head.)
+                    std::lock_guard<std::mutex> g(oom_mu_);
+                    trim(std::max<std::size_t>(bytes, std::size_t(2) << 30));
+                }
+                std::lock_guard<std::mutex> g(mu_);
+                free_[{ stream, bytes }].push_back({ p, ++clock_ });
+                cached_ += bytes;
             }
-            // gives cached blocks back to the device until `at_least` bytes are returned (everything by default): the blocks below
-            // 256 MiB first, least recently released first among them, then the large ones in the same order.  Getting a
-            // large block from the device again costs tens of milliseconds (measured: 40 ms per GiB), a small one next to
-            // nothing, and the large blocks are the packed ciphertexts that the next bootstrapping round wants back.
+            // gives cached blocks back to the device until `at_least` bytes are returned (everything by default), in this order:
+            //   1. blocks below 256 MiB whose free list (one stream, one size) has not served a request for a second,
+            //      least recently released first -- the leftovers of a stage that is over, or inputs that a running
+            //      stage releases and never asks for again;
+            //   2. blocks of 256 MiB and more, least recently released first -- packed ciphertexts: getting one from the device
+            //      again costs tens of milliseconds (measured: 40 ms per GiB), and the next bootstrapping round wants them back;
+            //   3. the small blocks of the lists that are serving requests -- what the running loops are cycling through (a
+            //      temporary of MOAI's multiply_plain + add_inplace loops lives for microseconds): giving those back makes the
+            //      very next request go to the device again.
             // Returns the bytes freed.
             std::size_t trim(std::size_t at_least = ~std::size_t(0))
             {
                 constexpr std::size_t large = std::size_t(256) << 20;
+                const double hot_after = now_seconds() - 1.0;
                 std::vector<void *> victims;
                 std::size_t freed = 0;
                 {
@@ -347,16 +365,25 @@ namespace seal
                         std::uint64_t tick;
                         std::size_t bytes;
                     };
+                    auto class_of = [&](const std::pair<void *, std::size_t> &list) {
+                        if (list.second >= large)
+                        {
+                            return 1;
+                        }
+                        auto hit = last_hit_.find(list);
+                        return hit != last_hit_.end() && hit->second >= hot_after ? 2 : 0;
+                    };
                     std::vector<Age> ages;
                     for (auto &kv : free_)
                     {
+                        const int cls = class_of(kv.first);
                         for (auto &blk : kv.second)
                         {
-                            ages.push_back({ kv.first.second >= large ? 1 : 0, blk.tick, kv.first.second });
+                            ages.push_back({ cls, blk.tick, kv.first.second });
                         }
                     }
                     std::sort(ages.begin(), ages.end(), [](const Age &a, const Age &b) { return a.cls != b.cls ? a.cls < b.cls : a.tick < b.tick; });
-                    std::uint64_t newest_victim[2] = { 0, 0 };
+                    std::uint64_t newest_victim[3] = { 0, 0, 0 };
                     for (auto &a : ages)
                     {
                         if (freed >= at_least)
@@ -368,8 +395,9 @@ namespace seal
                     }
                     for (auto it = free_.begin(); it != free_.end();)
                     {
-                        auto &list = it->second; // one size, so one class; ticks ascend within a list: the victims are a prefix
-                        const std::uint64_t cut = newest_victim[it->first.second >= large ? 1 : 0];
+                        // one class per list, ticks ascend within it: the victims are a prefix
+                        auto &list = it->second;
+                        const std::uint64_t cut = newest_victim[class_of(it->first)];
                         std::size_t k = 0;
                         while (k < list.size() && list[k].tick <= cut)
                         {
@@ -393,6 +421,10 @@ namespace seal
                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), cached_bytes() / 1073741824.0);
                 }
                 return freed;
+            }
+            static double now_seconds()
+            {
+                return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
             }
             std::size_t cached_bytes()
             {
@@ -421,6 +453,7 @@ namespace seal
                 std::uint64_t tick; // value of clock_ when it was released
             };
             std::map<std::pair<void *, std::size_t>, std::vector<Block>> free_;
+            std::map<std::pair<void *, std::size_t>, double> last_hit_; // when a list last served a request
             std::size_t cached_ = 0, cap_ = 0;
             std::uint64_t clock_ = 0;
             std::atomic<std::uint64_t> fresh_count_{ 0 }, fresh_us_{ 0 };

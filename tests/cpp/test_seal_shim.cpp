@@ -620,18 +620,33 @@ static void device_pool()
     pool.release(b2, g2, nullptr);
     CHECK(pool.trim(MB + 1) == 3 * MB); // whole blocks, oldest first, until at least that much is back
     CHECK(pool.trim() == 0);
-    // blocks of 256 MiB and more are the last to go, however old: they cost the most to get back from the device
+    // order of giving back: small blocks whose free list is not serving requests, then the blocks of 256 MiB and more, then the
+    // small blocks of lists that served a request within the last second (what a running loop is cycling through)
     const size_t big = size_t(256) << 20;
-    size_t gl = 0, gs = 0;
-    void *l = pool.acquire(big, nullptr, &gl), *sm = pool.acquire(MB, nullptr, &gs);
-    pool.release(l, gl, nullptr); // the older one
-    pool.release(sm, gs, nullptr);
-    CHECK(pool.trim(1) == MB);
-    CHECK(pool.cached_bytes() == big);
-    size_t g3 = 0;
-    CHECK(pool.acquire(big, nullptr, &g3) == l);
-    pool.release(l, g3, nullptr);
-    CHECK(pool.trim(1) == big);
+    size_t gl = 0, gs1 = 0, gs2 = 0;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1200)); // the lists used above become idle
+    void *s1 = pool.acquire(MB, nullptr, &gs1), *l = pool.acquire(big, nullptr, &gl), *s2 = pool.acquire(2 * MB, nullptr, &gs2);
+    pool.release(s1, gs1, nullptr);
+    pool.release(l, gl, nullptr);
+    pool.release(s2, gs2, nullptr);
+    s2 = pool.acquire(2 * MB, nullptr, &gs2); // the 2 MiB list serves a request: it is in use
+    pool.release(s2, gs2, nullptr);
+    CHECK(pool.trim(1) == MB); // the idle small list first
+    CHECK(pool.cached_bytes() == big + 2 * MB);
+    CHECK(pool.trim(1) == big); // then the large block
+    CHECK(pool.cached_bytes() == 2 * MB);
+    CHECK(pool.trim(1) == 2 * MB);
+    CHECK(pool.cached_bytes() == 0);
+    // ... and an idle list stops being protected
+    s2 = pool.acquire(2 * MB, nullptr, &gs2);
+    l = pool.acquire(big, nullptr, &gl);
+    pool.release(s2, gs2, nullptr);
+    s2 = pool.acquire(2 * MB, nullptr, &gs2);
+    pool.release(s2, gs2, nullptr);
+    pool.release(l, gl, nullptr);
+    std::this_thread::sleep_for(std::chrono::milliseconds(1200));
+    CHECK(pool.trim(1) == 2 * MB);
+    CHECK(pool.trim() == big);
 }
 
 int main()

@@ -235,12 +235,18 @@ int main(int argc, char **argv)
         printf("768 input ciphertexts encrypted and switched to chain index 15: %.1f s\n", now_s() - t0);
         report_memory("start of the attention head");
         moai_op_trace(1);
+        const auto fresh0 = seal::util::DevicePool::instance().fresh_allocations();
         t0 = now_s();
         vector<Ciphertext> out = single_att_block(enc_X, WQ, WK, WV, bQ, bK, bV, b_vec, input_num, context, relin_keys, gal_keys, bootstrapper,
                                                   num_X, secret_key, iter, layer_id);
         context.sync();
         head_s = now_s() - t0;
         moai_op_trace(0);
+        {
+            const auto fresh1 = seal::util::DevicePool::instance().fresh_allocations();
+            printf("  [device allocations during the head: %llu, %.0f ms in them; the other requests were served from the cache]\n",
+                   (unsigned long long)(fresh1.first - fresh0.first), fresh1.second - fresh0.second);
+        }
         ops_head = census_json();
         // the same head in the clear with MOAI's approximations (tests/cpp/test_moai_attention.cpp explains the model)
         auto approx_exp = [](double x) { return pow(1 + x * 0.0078125, 128); };

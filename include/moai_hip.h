@@ -242,6 +242,12 @@ int moai_apply_galois(moai_ctx *ctx, uint64_t *ct, size_t L, uint32_t galois_elt
  * without the deep copy): in, out: [batch][2][L][N]; out may be in. */
 int moai_apply_galois_to(moai_ctx *ctx, const uint64_t *in, uint64_t *out, size_t L, uint32_t galois_elt,
                          const uint64_t *galois_key, size_t batch, void *stream);
+/* acc = add_inplace(acc, apply_galois(in)): a rotation whose result is added to a running sum, the pair
+ * rotate_vector + add_inplace_reduced_error (equal levels) of the giant steps of Bootstrapper::bsgs_linear_transform
+ * (include/source/bootstrapping/Bootstrapper.cpp:2049-2059); the addition rides on the key switch's last kernel.
+ * in, acc: [batch][2][L][N], distinct.  Same residues as moai_apply_galois_to followed by moai_add. */
+int moai_apply_galois_acc(moai_ctx *ctx, const uint64_t *in, uint64_t *acc, size_t L, uint32_t galois_elt,
+                          const uint64_t *galois_key, size_t batch, void *stream);
 
 /* ---- MOAI-owned integer kernel ---------------------------------------------------------------------------
  * Bootstrapper::modraise_inplace include/source/bootstrapping/Bootstrapper.cpp:2938-2992:

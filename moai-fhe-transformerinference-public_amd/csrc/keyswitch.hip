@@ -114,6 +114,7 @@ struct FinalizeArgs
     uint32_t Lout;
     uint32_t n2;
     const uint64_t *addend; // see ModDownArgs
+    const uint64_t *addend2;
     uint32_t addend_bstride;
     int add_mode;
 };
@@ -137,6 +138,12 @@ __global__ __launch_bounds__(256) void moddown_finalize_kernel(FinalizeArgs g)
         {
             ulonglong2 c = (reinterpret_cast<const ulonglong2 *>(g.addend) +
                             ((size_t)(p >> 1) * g.addend_bstride + (size_t)(p & 1u) * g.Lout + i) * g.n2)[j];
+            r.x = csub(r.x + c.x, q);
+            r.y = csub(r.y + c.y, q);
+        }
+        if (g.addend2)
+        {
+            ulonglong2 c = (reinterpret_cast<const ulonglong2 *>(g.addend2) + (size_t)blockIdx.y * g.n2)[j];
             r.x = csub(r.x + c.x, q);
             r.y = csub(r.y + c.y, q);
         }
@@ -270,9 +277,11 @@ static inline size_t align256(size_t x)
 //   acc row (p, i) = acc + (p * acc_stride + i) * N ; out [P][Lout][N]
 // scratch: u [P][Lout][N]
 //   addend / addend_bstride / add_mode: what is added to the quotient (ModDownArgs); add_mode 0 for rescale
+//   addend2: a second summand with the output's layout (may be `out`), or null
 static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32_t acc_stride, uint64_t *u,
                    uint64_t *out, size_t P, size_t Lout, uint32_t prime_last, const uint64_t *addend, uint32_t addend_bstride,
-                   int add_mode, hipStream_t s, uint32_t acc_splits = 1, size_t acc_split_stride = 0, const Tw *scal = nullptr)
+                   int add_mode, hipStream_t s, uint32_t acc_splits = 1, size_t acc_split_stride = 0, const Tw *scal = nullptr,
+                   const uint64_t *addend2 = nullptr)
 {
     RowMap rm;
     uint32_t pl = prime_last;
@@ -303,6 +312,7 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
         a.Lout = (uint32_t)Lout;
         a.P = (uint32_t)P;
         a.addend = addend;
+        a.addend2 = addend2;
         a.addend_bstride = addend_bstride;
         a.add_mode = add_mode;
         a.has_scal = scal ? 1 : 0;
@@ -403,6 +413,7 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
     f.Lout = (uint32_t)Lout;
     f.n2 = (uint32_t)(c->n >> 1);
     f.addend = addend;
+    f.addend2 = addend2;
     f.addend_bstride = addend_bstride;
     f.add_mode = add_mode;
     MOAI_CHECK_GRID_ROWS(P * Lout);
@@ -581,7 +592,7 @@ static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const u
 // ct [batch][2][L][N] = addend (add_mode, ModDownArgs) + key switch of `target`; ct may be the addend itself
 static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, size_t target_stride_rows,
                            size_t target_off_rows, const uint64_t *key, size_t L, size_t batch, void *wsp,
-                           hipStream_t s, const uint64_t *addend, size_t addend_bstride, int add_mode)
+                           hipStream_t s, const uint64_t *addend, size_t addend_bstride, int add_mode, const uint64_t *addend2 = nullptr)
 {
     const size_t n = c->n;
     const size_t k = c->k;
@@ -732,7 +743,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
                        split_stride, c->pc, (uint32_t)(k - 1), n2);
     MOAI_LAUNCH_CHECK();
     return moddown(c, last, acc, (uint32_t)(L + 1), ops, ct, batch * 2, L, (uint32_t)(k - 1), addend, (uint32_t)addend_bstride, add_mode, s, splits,
-                   split_stride);
+                   split_stride, nullptr, addend2);
 }
 
 } // namespace moai
@@ -974,6 +985,44 @@ extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t g
                                  size_t batch, void *stream)
 {
     return moai_apply_galois_to(c, ct, ct, L, galois_elt, galois_key, batch, stream);
+}
+
+extern "C" int moai_apply_galois_acc(moai_ctx *c, const uint64_t *in, uint64_t *acc, size_t L, uint32_t galois_elt,
+                                     const uint64_t *galois_key, size_t batch, void *stream)
+{
+    trace_op("apply_galois_to", L, batch); // the same key switch; the addition that follows it is what is saved
+    int rc = check_level(c, L, batch * 2);
+    if (rc)
+    {
+        return rc;
+    }
+    if (batch == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!in || !acc || !galois_key || in == acc)
+    {
+        return set_error(MOAI_EINVAL, "null argument, or the sum is the input");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_bytes = c->n * sizeof(uint64_t);
+    const size_t sz_tmp = align256(batch * 2 * L * row_bytes);
+    std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
+    void *wsp;
+    rc = workspace(c, sz_tmp + switch_key_ws_bytes(c, L, batch), s, &wsp);
+    if (rc)
+    {
+        return rc;
+    }
+    uint64_t *tmp = static_cast<uint64_t *>(wsp);
+    void *ks_ws = static_cast<char *>(wsp) + sz_tmp;
+    rc = moai_galois_permute(c, in, tmp, batch * 2, L, galois_elt, stream);
+    if (rc)
+    {
+        return rc;
+    }
+    // acc = acc + (tmp0, 0) + switch_key(tmp1): both summands are added by the key switch's last kernel
+    return switch_key_impl(c, acc, tmp, 2 * L, L, galois_key, L, batch, ks_ws, s, tmp, 2 * L, 2, acc);
 }
 
 extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream)

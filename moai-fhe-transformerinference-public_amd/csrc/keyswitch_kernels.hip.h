@@ -729,6 +729,7 @@ struct StoreModDown
     const ulonglong2 *acc; // tile base of the row being divided (first of `splits` partial copies)
     ulonglong2 *out;       // tile base of the result row
     const ulonglong2 *add; // tile base of the row to add to the result (key switch), or nullptr (rescale)
+    const ulonglong2 *add2; // tile base of a second row to add (a sum that the result is accumulated into), or nullptr
     uint64_t q;
     Tw inv;
     Tw sc;                 // use_sc: the divided row is acc * sc mod q (a scalar plaintext product fused into the rescale)
@@ -758,6 +759,12 @@ struct StoreModDown
             r.x = csub(r.x + c.x, q);
             r.y = csub(r.y + c.y, q);
         }
+        if (add2)
+        {
+            ulonglong2 c = add2[ch];
+            r.x = csub(r.x + c.x, q);
+            r.y = csub(r.y + c.y, q);
+        }
         out[ch] = r;
     }
 };
@@ -783,6 +790,7 @@ struct ModDownArgs
     const uint64_t *addend;
     uint32_t addend_bstride;
     int add_mode;
+    const uint64_t *addend2; // or null: [P][Lout][N] like out (may be out itself), added to every polynomial after `addend`
     uint32_t acc_splits;     // >= 1
     size_t acc_split_stride; // words between partial copies of acc
     uint32_t total_work;
@@ -855,6 +863,7 @@ __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
         st.add = reinterpret_cast<const ulonglong2 *>(a.addend + (((size_t)(p >> 1) * a.addend_bstride + (size_t)(p & 1u) * a.Lout + i) << LOGN)) +
                  ((size_t)tile << 11);
     }
+    st.add2 = a.addend2 ? reinterpret_cast<const ulonglong2 *>(a.addend2 + (((size_t)p * a.Lout + i) << LOGN)) + ((size_t)tile << 11) : nullptr;
     st.splits = a.acc_splits;
     st.split_stride = a.acc_split_stride >> 1;
     st.use_sc = a.has_scal;

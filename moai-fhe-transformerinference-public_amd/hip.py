@@ -64,6 +64,7 @@ SYMBOLS = {
     "moai_relinearize": (C.c_int, [vp, vp, vp, vp, sz, sz, vp]),
     "moai_apply_galois": (C.c_int, [vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_apply_galois_to": (C.c_int, [vp, vp, vp, sz, C.c_uint32, vp, sz, vp]),
+    "moai_apply_galois_acc": (C.c_int, [vp, vp, vp, sz, C.c_uint32, vp, sz, vp]),
     "moai_modraise": (C.c_int, [vp, vp, vp, sz, sz, vp]),
     "moai_hoist_correction": (C.c_int, [vp, vp, C.c_uint32, sz, vp, vp]),
     "moai_apply_galois_hoisted": (C.c_int, [vp, vp, C.POINTER(vp), sz, C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(vp), sz, sz, C.POINTER(C.c_int), vp]),
@@ -302,6 +303,9 @@ class Context:
 
     def relinearize(self, ct3, key, out, L, batch, stream=None):
         _check(lib().moai_relinearize(self.h, _ptr(ct3), _ptr(key), _ptr(out), L, batch, stream))
+
+    def apply_galois_acc(self, src, acc, L, elt, key, batch, stream=None):
+        _check(lib().moai_apply_galois_acc(self.h, _ptr(src), _ptr(acc), L, int(elt), _ptr(key), batch, stream))
 
     def apply_galois(self, ct, L, elt, key, batch, stream=None):
         _check(lib().moai_apply_galois(self.h, _ptr(ct), L, int(elt), _ptr(key), batch, stream))

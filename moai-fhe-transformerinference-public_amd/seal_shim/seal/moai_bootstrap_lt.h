@@ -297,6 +297,22 @@ namespace moai_fused
             bool first = true;
             std::vector<std::uint32_t> xi, pi, pi2;
             auto fold = [&](std::uint64_t *dst, const Giant &g) {
+                if (g.step != 0 && !first)
+                {
+                    // the rotation's last key switch adds its result to the running sum itself (moai_apply_galois_acc)
+                    seq.clear();
+                    detail::rotation_sequence(context_, gal_keys, g.step, seq);
+                    if (!seq.empty())
+                    {
+                        for (std::size_t h = 0; h + 1 < seq.size(); h++)
+                        {
+                            util::hip_check(moai_apply_galois(dev, dst, L, seq[h], gal_keys.device_key(seal::GaloisKeys::get_index(seq[h])), B, st));
+                        }
+                        util::hip_check(moai_apply_galois_acc(dev, dst, acc.get(), L, seq.back(),
+                                                              gal_keys.device_key(seal::GaloisKeys::get_index(seq.back())), B, st));
+                        return;
+                    }
+                }
                 if (g.step != 0)
                 {
                     rotate_batch(dst, g.step, L, B, gal_keys, seq);

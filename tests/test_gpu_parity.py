@@ -437,6 +437,15 @@ def test_switch_key_relin_galois(moai, env12, L, ks_arith):
         got = dct.to_numpy(ct.shape)
         for b in range(B):
             assert (got[b] == octx.apply_galois(ct[b], L, elt, key).reshape(2, L, n)).all()
+        # accumulated into a running sum by the key switch's last kernel (moai_apply_galois_acc): rotation + add_inplace
+        run = O.uniform_rns(rng, primes[:L], (B, 2), n)
+        drun, dsrc = up(moai, run), up(moai, ct)
+        ctx.apply_galois_acc(dsrc, drun, L, elt, dkey, B)
+        got_acc = drun.to_numpy(ct.shape)
+        for b in range(B):
+            want_acc = octx.add(run[b], octx.apply_galois(ct[b], L, elt, key).reshape(2, L, n), 2, L).reshape(2, L, n)
+            assert (got_acc[b] == want_acc).all(), (elt, b)
+        assert (dsrc.to_numpy(ct.shape) == ct).all()
         # separate destination: same result, source untouched
         dsrc, ddst = up(moai, ct), moai.DeviceBuffer(ct.size)
         ctx.apply_galois_to(dsrc, ddst, L, elt, dkey, B)

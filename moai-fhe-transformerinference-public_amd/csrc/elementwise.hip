@@ -276,7 +276,82 @@ struct MatmulArgs
     uint64_t *out;       // [cols][size][L][N]
     const PrimeConst *pc;
     uint32_t rows, cols, size, L, n2;
+    const double *wd;    // the same weights as doubles (ct_pt_matmul_fp_kernel)
 };
+
+// The same sums in exact FP64 arithmetic for primes below 2^51 (every data prime of MOAI's chain): a product of two residues
+// is formed as a rounded high part and its exact remainder (fp_mulmod_q) and reduced at once; the sums are folded every
+// sixteen rows below 2^52 / 25 and every row otherwise, so every intermediate is an integer below 2^53 -- exact, hence the
+// same canonical residues as the integer kernel.  Seven full-rate FP64 operations per product against a 64 x 64 -> 128-bit
+// integer multiply-accumulate built from quarter-rate 32-bit multiplies, and half the accumulator registers.
+template <int CG>
+__global__ __launch_bounds__(256) void ct_pt_matmul_fp_kernel(MatmulArgs g)
+{
+    const uint32_t pr = blockIdx.y; // p * L + r
+    const uint32_t r = pr % g.L;
+    const uint32_t c0 = blockIdx.z * CG;
+    const PrimeConst *pc = g.pc + r;
+    const double qd = u2d(pc->qd), qinv = u2d(pc->qinv);
+    const bool every_row = !(pc->q < ((1ull << 52) / 25));
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.n2)
+    {
+        return;
+    }
+    const size_t poly_stride = (size_t)g.size * g.L * g.n2;
+    const ulonglong2 *__restrict__ x2 = reinterpret_cast<const ulonglong2 *>(g.x) + (size_t)pr * g.n2 + i;
+    const double *__restrict__ wr = g.wd + (size_t)r * g.rows * g.cols + c0;
+    double ax[CG], ay[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+    {
+        ax[c] = ay[c] = 0.0;
+    }
+    for (uint32_t j = 0; j < g.rows; ++j)
+    {
+        const ulonglong2 v = x2[(size_t)j * poly_stride];
+        const double vx = fp_red(fp_from_u52(v.x), qd, qinv), vy = fp_red(fp_from_u52(v.y), qd, qinv);
+        const double *__restrict__ wj = wr + (size_t)j * g.cols;
+        const bool fold = every_row || (j & 15u) == 15u;
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+        {
+            if (c0 + c < g.cols)
+            {
+                const double wv = wj[c];
+                double sx = ax[c] + fp_mulmod_q(vx, wv, qd, qinv);
+                double sy = ay[c] + fp_mulmod_q(vy, wv, qd, qinv);
+                if (fold)
+                {
+                    sx = fp_red(sx, qd, qinv);
+                    sy = fp_red(sy, qd, qinv);
+                }
+                ax[c] = sx;
+                ay[c] = sy;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+    {
+        if (c0 + c < g.cols)
+        {
+            ulonglong2 o;
+            o.x = fp_to_canonical(ax[c], qd, qinv);
+            o.y = fp_to_canonical(ay[c], qd, qinv);
+            reinterpret_cast<ulonglong2 *>(g.out)[((size_t)(c0 + c) * g.size * g.L + pr) * g.n2 + i] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void u52_to_f64_kernel(const uint64_t *in, double *out, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < count)
+    {
+        out[i] = fp_from_u52(in[i]);
+    }
+}
 
 template <int CG>
 __global__ __launch_bounds__(256) void ct_pt_matmul_kernel(MatmulArgs g)
@@ -1280,8 +1355,33 @@ extern "C" int moai_ct_pt_matmul(moai_ctx *c, const uint64_t *x, const uint64_t 
     g.size = (uint32_t)size;
     g.L = (uint32_t)L;
     g.n2 = (uint32_t)(c->n >> 1);
+    g.wd = nullptr;
     dim3 grid((g.n2 + 255u) / 256u, (uint32_t)(size * L), (uint32_t)((cols + CG - 1) / CG));
-    hipLaunchKernelGGL(ct_pt_matmul_kernel<CG>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    // exact FP64 sums when every prime of the level is below 2^51 (MOAI_MATMUL_FP=0: the integer kernel)
+    bool fp = tuning("MOAI_MATMUL_FP", 1) != 0;
+    for (size_t r = 0; r < L && fp; r++)
+    {
+        fp = c->primes[r] < (1ull << 51);
+    }
+    if (fp)
+    {
+        hipStream_t s = (hipStream_t)stream;
+        const size_t count = L * rows * cols;
+        std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
+        void *wsp;
+        rc = workspace(c, count * sizeof(double), s, &wsp);
+        if (rc)
+        {
+            return rc;
+        }
+        g.wd = static_cast<const double *>(wsp);
+        hipLaunchKernelGGL(u52_to_f64_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, w, static_cast<double *>(wsp), count);
+        hipLaunchKernelGGL(ct_pt_matmul_fp_kernel<CG>, grid, dim3(256), 0, s, g);
+    }
+    else
+    {
+        hipLaunchKernelGGL(ct_pt_matmul_kernel<CG>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    }
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
 }

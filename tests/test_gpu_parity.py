@@ -698,7 +698,7 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("bits,rows,cols", [([51, 46, 46, 58], 70, 19), ([60, 61, 60], 33, 5), ([46, 51], 3, 16)])
+@pytest.mark.parametrize("bits,rows,cols", [([51, 46, 46, 58], 70, 19), ([60, 61, 60], 33, 5), ([46, 51], 3, 16), ([51, 51, 47, 58], 48, 33)])
 def test_ct_pt_matmul_matches_multiply_plain_loop(moai, bits, rows, cols):
     """moai_ct_pt_matmul == the reference loop of multiply_plain(scalar plaintext) + add_inplace
     (Ct_pt_matrix_mul.hpp:19-38), including the 32-term accumulator folds and ragged column groups."""
@@ -712,12 +712,20 @@ def test_ct_pt_matmul_matches_multiply_plain_loop(moai, bits, rows, cols):
     w = np.empty((L, rows, cols), dtype=np.uint64)
     for r in range(L):
         w[r] = rng.integers(0, primes[r], size=(rows, cols), dtype=np.uint64)
-    w[:, 0, 0] = [q - 1 for q in primes[:L]]
-    x[0, :, :, :8] = np.array([q - 1 for q in primes[:L]], dtype=np.uint64)[None, :, None]
+    # worst-case magnitudes: q-1 in the first coefficients of EVERY row against a column of q-1 weights
+    w[:, :, 0] = np.array([q - 1 for q in primes[:L]], dtype=np.uint64)[:, None]
+    x[:, :, :, :8] = np.array([q - 1 for q in primes[:L]], dtype=np.uint64)[None, None, :, None]
     dx, dw = up(moai, x), up(moai, w)
     dout = moai.DeviceBuffer(cols * 2 * L * n)
     ctx.ct_pt_matmul(dx, dw, dout, rows, cols, 2, L)
     got = dout.to_numpy((cols, 2, L, n))
+    # primes below 2^51 take the exact-FP64 kernel, the others the integer one; with the FP64 kernel switched off: the same bits
+    moai.hip.set_tuning("MOAI_MATMUL_FP", 0)
+    try:
+        ctx.ct_pt_matmul(dx, dw, dout, rows, cols, 2, L)
+        assert (dout.to_numpy((cols, 2, L, n)) == got).all()
+    finally:
+        moai.hip.set_tuning("MOAI_MATMUL_FP", 1)
     for c in (0, cols // 2, cols - 1):
         acc = np.zeros((2, L, n), dtype=np.uint64)
         for j in range(rows):

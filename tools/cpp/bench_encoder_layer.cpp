@@ -53,6 +53,7 @@ int main(int argc, char **argv)
     const int boot_B = argc > 4 ? atoi(argv[4]) : 48; // must divide 768; 63.8 ms per bootstrap at 48, 65.6 ms at 16
     const int boot_packs = argc > 2 ? atoi(argv[2]) : 768 / boot_B;
     const int gelu_packs = argc > 3 ? atoi(argv[3]) : 48;
+    const int layers = argc > 5 ? atoi(argv[5]) : 1; // consecutive layers: the output of one is the input of the next
     omp_set_num_threads(16);
     EncryptionParameters parms(scheme_type::ckks);
     const size_t n = 65536;
@@ -180,6 +181,12 @@ int main(int argc, char **argv)
     context.sync();
     fprintf(stderr, "layer input: %d ciphertexts at chain index %zu\n", num_col, context.get_context_data(enc_ecd_x[0].parms_id())->chain_index());
 
+    for (int layer = 0; layer < layers; layer++)
+    {
+    if (layers > 1)
+    {
+        fprintf(stderr, "---- layer %d of %d (fresh synthetic weights; input = the previous layer's output) ----\n", layer + 1, layers);
+    }
     const double t_layer = now_s();
     double t_att = 0, t_boot = 0;
     // ---- attention: 12 heads -------------------------------------------------------------------------------------------
@@ -389,6 +396,10 @@ int main(int argc, char **argv)
     if (full)
     {
         fprintf(stderr, "x 12 layers = %.0f s per batch of 256 inputs = %.2f s per encrypted input (paper: 574.6 s on 56 cores)\n", total * 12, total * 12 / 256);
+    }
+    // test_full_scheme.hpp:1084-1086: the last bootstrapping round writes the next layer's input
+    enc_ecd_x = std::move(work);
+    enc_ecd_x_copy = enc_ecd_x;
     }
     return 0;
 }

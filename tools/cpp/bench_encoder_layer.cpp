@@ -397,6 +397,26 @@ int main(int argc, char **argv)
     {
         fprintf(stderr, "x 12 layers = %.0f s per batch of 256 inputs = %.2f s per encrypted input (paper: 574.6 s on 56 cores)\n", total * 12, total * 12 / 256);
     }
+    {
+        // what the layer hands on: the first output ciphertext decrypted, over the slots that carry tokens (LayerNorm 2's
+        // output through a bootstrap: values of order one if everything before it stayed inside its approximation ranges)
+        Plaintext pt;
+        decryptor.decrypt(work[0], pt);
+        vector<double> vals;
+        encoder.decode(pt, vals);
+        double mx = 0, sum = 0;
+        size_t cnt = 0;
+        for (size_t sidx = 0; sidx < slots; sidx++)
+        {
+            if (b_vec[sidx])
+            {
+                mx = max(mx, fabs(vals[sidx]));
+                sum += fabs(vals[sidx]);
+                cnt++;
+            }
+        }
+        fprintf(stderr, "layer output, ciphertext 0 decrypted: max |value| %.3f, mean |value| %.3f over %zu token slots\n", mx, sum / max<size_t>(cnt, 1), cnt);
+    }
     // test_full_scheme.hpp:1084-1086: the last bootstrapping round writes the next layer's input
     enc_ecd_x = std::move(work);
     enc_ecd_x_copy = enc_ecd_x;

@@ -285,7 +285,7 @@ int main(int argc, char **argv)
     }
     t_boot += bootstrap_round(work, "bootstrap round 1");
     // ---- residual + LayerNorm 1 -------------------------------------------------------------------------------------------
-    vector<double> gamma(num_col, 1.0), beta(num_col, 0.1);
+    vector<double> gamma(num_col, 0.5), beta(num_col, 0.05); // LayerNorm hands on values with the spread of the synthetic layer input (standard deviation 0.5), so that consecutive layers see what the first one sees
     double t_ln1;
     {
         t0 = now_s();

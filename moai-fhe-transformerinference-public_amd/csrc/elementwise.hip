@@ -283,7 +283,7 @@ struct MatmulArgs
 // is formed as a rounded high part and its exact remainder (fp_mulmod_q) and reduced at once; the sums are folded every
 // sixteen rows below 2^52 / 25 and every row otherwise, so every intermediate is an integer below 2^53 -- exact, hence the
 // same canonical residues as the integer kernel.  Seven full-rate FP64 operations per product against a 64 x 64 -> 128-bit
-// integer multiply-accumulate built from quarter-rate 32-bit multiplies, and half the accumulator registers.
+// integer multiply-accumulate (a dozen 32-bit multiply-class and carry instructions), and half the accumulator registers.
 template <int CG>
 __global__ __launch_bounds__(256) void ct_pt_matmul_fp_kernel(MatmulArgs g)
 {

@@ -21,7 +21,8 @@
 //    654-660).  Concurrent callers are gathered into ONE packed run (leader / followers, bounded waits): every ciphertext
 //    gets exactly the result of its own call -- the packed kernels compute each member independently, bit-identical to
 //    a single-ciphertext run (tests/cpp/test_bootstrap_real.cpp) -- but the device sees batches of the caller count.
-//    MOAI_BOOT_COMBINE_US sets the gathering window (default 2000 us; 0 = never gather), MOAI_BOOT_MAX_PACK the
+//    MOAI_BOOT_COMBINE_US sets the gathering window (default 8000 us -- a caller without company waits a quarter of it, 0.1 % of
+//    a packed run and 1.5 % of a single bootstrap; 0 = never gather), MOAI_BOOT_MAX_PACK the
 //    largest pack (default 48).
 #pragma once
 
@@ -95,7 +96,7 @@ public:
         mod_reducer = new ModularReducer(boundary_K, static_cast<double>(loge), sin_cos_deg, scale_factor, inverse_deg, context, encoder,
                                          encryptor, evaluator, relin_keys, decryptor);
         const char *e = std::getenv("MOAI_BOOT_COMBINE_US");
-        combine_us_ = e ? std::atol(e) : 2000;
+        combine_us_ = e ? std::atol(e) : 8000;
         e = std::getenv("MOAI_BOOT_MAX_PACK");
         max_pack_ = e ? static_cast<std::size_t>(std::atol(e)) : 48;
         if (max_pack_ < 1)

@@ -295,7 +295,7 @@ def end_to_end_slice(args, cores):
         return {"skipped": "tools/cpp/bench_e2e is not built on this machine"}
     t0 = time.perf_counter()
     try:
-        r = subprocess.run([exe, str(args.e2e_pack), str(max(host_cores(), args.e2e_pack))], cwd=os.path.dirname(exe), capture_output=True, text=True,
+        r = subprocess.run([exe, str(args.e2e_pack), str(host_cores())], cwd=os.path.dirname(exe), capture_output=True, text=True,
                            timeout=args.e2e_timeout)
     except subprocess.TimeoutExpired:
         return {"skipped": "bench_e2e exceeded %.0f s" % args.e2e_timeout}

@@ -170,8 +170,11 @@ int main(int argc, char **argv)
     moai_op_trace(0);
     const string ops_boot = census_json();
     vector<Ciphertext> outs(pack);
+    // MOAI's loop over the ciphertexts of a bootstrapping round (test_full_scheme.hpp:654-660) runs on every core of its 56-core
+    // host; here as many callers as the pack holds, so that the drop-in can gather a full pack (the host threads only wait)
+    const int boot_threads = max(threads, pack);
     t0 = now_s();
-#pragma omp parallel for
+#pragma omp parallel for num_threads(boot_threads)
     for (int i = 0; i < pack; i++)
     {
         Ciphertext c = low[i];
@@ -191,7 +194,7 @@ int main(int argc, char **argv)
     const size_t boot_index = context.get_context_data(outs[0].parms_id())->chain_index();
     printf("bootstrap_3: %.2f ms per ciphertext in one pack of %d; %.2f ms through %d single-ciphertext calls from %d threads; "
            "chain index 0 -> %zu, max |error| %.2e\n",
-           boot_packed_ms, pack, boot_calls_ms, pack, threads, boot_index, boot_err);
+           boot_packed_ms, pack, boot_calls_ms, pack, boot_threads, boot_index, boot_err);
     report_memory("end of the bootstrapping part");
     low.clear();
     outs.clear();

@@ -304,12 +304,29 @@ int moai_set_tuning(const char *name, long value);
  * otherwise makes the R separate calls itself (*used_fallback = 1).
  *   in, outs[r]  [batch][2][L][N] (no output may alias the input)   correction [2][L+1][N] (rows 0..L-1 under primes
  *   0..L-1, row L under the special prime), computed for the same (key, galois_elt, L).  outs / galois_keys /
- *   corrections: host arrays of R device pointers. */
+ *   corrections: host arrays of R device pointers.
+ * Any R: the accumulators of one pass hold 64 rotations, more are done 64 at a time (one decomposition per pass).
+ * The call SYNCHRONISES the stream once (it reads the zero-coefficient flag back): unlike the other key-switch entry
+ * points it cannot run under HIP-graph stream capture. */
 int moai_hoist_correction(moai_ctx *ctx, const uint64_t *galois_key, uint32_t galois_elt, size_t L, uint64_t *correction,
                           void *stream);
 int moai_apply_galois_hoisted(moai_ctx *ctx, const uint64_t *in, uint64_t *const *outs, size_t L, const uint32_t *galois_elts,
                               const uint64_t *const *galois_keys, const uint64_t *const *corrections, size_t R, size_t batch,
                               int *used_fallback, void *stream);
+
+/* ---- stream audit (debug) ----------------------------------------------------------------------------------------
+ * A caller that recycles device blocks in a stream-ordered cache (the seal:: shim's util::DevicePool: a released block may be
+ * handed out again on the SAME stream without synchronising, which is only safe when everything that touches the block is
+ * enqueued on that stream) can have that invariant checked.  With MOAI_STREAM_AUDIT=1 in the environment, or after
+ * moai_debug_stream_audit(1), moai_debug_block_label records the stream a block belongs to (state 1 = in use, 2 = released to
+ * the cache, 0 = forget: back to the device allocator), and every entry point above that enqueues work fails with MOAI_ELOGIC
+ * (and a line on stderr naming the function, the pointer and both streams) when handed a device pointer inside a block
+ * labelled with another stream or inside a released block.  Unlabelled memory is not checked.  The reference's counterpart is
+ * the single-threaded ownership of its MemoryPoolMT blocks (SEAL/util/mempool.h:228); it has no device streams.
+ * moai_debug_stream_audit returns the previous setting; _counts reports pointers checked / violations found so far. */
+int moai_debug_stream_audit(int enable);
+void moai_debug_block_label(const void *ptr, size_t bytes, const void *stream, int state);
+void moai_debug_stream_audit_counts(unsigned long long *checked, unsigned long long *violations);
 
 /* ---- operation census ----------------------------------------------------------------------------------------------
  * moai_op_trace(1) clears and starts, moai_op_trace(0) stops counting what the entry points above were asked to do:

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <initializer_list>
 #include <map>
 #include <string>
 #include <vector>
@@ -57,6 +59,26 @@ int set_error(int code, const char *fmt, ...);
     } while (0)
 
 #define MOAI_LAUNCH_CHECK() MOAI_HIP_CHECK(hipGetLastError())
+
+// Stream audit (debug; MOAI_STREAM_AUDIT=1 or moai_debug_stream_audit(1)).  A caller that keeps device blocks in a
+// stream-ordered cache (the seal:: shim's util::DevicePool) labels every block with the stream it belongs to
+// (moai_debug_block_label); every entry point that enqueues work then checks that each device pointer it was handed
+// lies in a block labelled with the stream the work is enqueued on, and is not a block that has been released.
+// An unlabelled pointer (plain moai_malloc memory, host arrays) is not checked.
+extern std::atomic<int> g_stream_audit;
+int audit_ptrs(const char *fn, const void *stream, std::initializer_list<const void *> ptrs);
+#define MOAI_AUDIT(stream, ...)                                                             \
+    do                                                                                      \
+    {                                                                                       \
+        if (::moai::g_stream_audit.load(std::memory_order_relaxed))                         \
+        {                                                                                   \
+            int _arc = ::moai::audit_ptrs(__func__, (const void *)(stream), { __VA_ARGS__ }); \
+            if (_arc)                                                                       \
+            {                                                                               \
+                return _arc;                                                                \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
 
 // row-per-block launches put the row count in gridDim.y, which HIP limits to 65535
 #define MOAI_CHECK_GRID_ROWS(rows)                                                                                   \

@@ -48,6 +48,68 @@ void trace_op(const char *name, size_t L, size_t units)
     g_trace[std::make_pair(std::string(name), L)] += units;
 }
 
+// ---- stream audit (common.h) ----------------------------------------------------------------------------------------
+std::atomic<int> g_stream_audit{ [] {
+    const char *e = getenv("MOAI_STREAM_AUDIT");
+    return e && e[0] != '0' ? 1 : 0;
+}() };
+struct AuditBlock
+{
+    size_t bytes;
+    const void *stream;
+    bool released;
+};
+static std::mutex g_audit_mu;
+static std::map<uintptr_t, AuditBlock> g_audit_blocks; // by base address
+static std::atomic<unsigned long long> g_audit_checked{ 0 }, g_audit_violations{ 0 };
+
+// one line at process exit, so that a run under MOAI_STREAM_AUDIT=1 shows that the audit was live and what it saw
+static struct AuditSummary
+{
+    ~AuditSummary()
+    {
+        if (g_stream_audit.load() || g_audit_checked.load())
+        {
+            fprintf(stderr, "[stream audit] %llu labelled pointers checked at enqueue, %llu violations\n", g_audit_checked.load(),
+                    g_audit_violations.load());
+        }
+    }
+} g_audit_summary;
+
+int audit_ptrs(const char *fn, const void *stream, std::initializer_list<const void *> ptrs)
+{
+    std::lock_guard<std::mutex> g(g_audit_mu);
+    for (const void *p : ptrs)
+    {
+        if (!p)
+        {
+            continue;
+        }
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        auto it = g_audit_blocks.upper_bound(a);
+        if (it == g_audit_blocks.begin())
+        {
+            continue;
+        }
+        --it;
+        if (a >= it->first + it->second.bytes)
+        {
+            continue; // not in a labelled block
+        }
+        g_audit_checked.fetch_add(1, std::memory_order_relaxed);
+        if (it->second.released || it->second.stream != stream)
+        {
+            g_audit_violations.fetch_add(1, std::memory_order_relaxed);
+            fprintf(stderr, "[stream audit] %s: pointer %p (block %p + %zu, %zu bytes) %s stream %p, work enqueued on stream %p\n", fn, p,
+                    (void *)it->first, (size_t)(a - it->first), it->second.bytes,
+                    it->second.released ? "was released to the cache of" : "belongs to", it->second.stream, stream);
+            return set_error(MOAI_ELOGIC, "stream audit: %s was handed %p, a block %s stream %p, to enqueue on stream %p", fn, p,
+                             it->second.released ? "released to the cache of" : "labelled with", it->second.stream, stream);
+        }
+    }
+    return MOAI_OK;
+}
+
 int enter_device(const moai_ctx *c)
 {
     MOAI_HIP_CHECK(hipSetDevice(c->device));
@@ -280,6 +342,42 @@ extern "C" size_t moai_op_trace_dump(char *buf, size_t cap)
         buf[nbytes] = 0;
     }
     return out.size() + 1;
+}
+
+extern "C" int moai_debug_stream_audit(int enable)
+{
+    const int was = moai::g_stream_audit.exchange(enable ? 1 : 0);
+    return was;
+}
+
+extern "C" void moai_debug_block_label(const void *ptr, size_t bytes, const void *stream, int state)
+{
+    if (!ptr || !moai::g_stream_audit.load(std::memory_order_relaxed))
+    {
+        return;
+    }
+    std::lock_guard<std::mutex> g(moai::g_audit_mu);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    if (state == 0)
+    {
+        moai::g_audit_blocks.erase(a); // back to the device allocator
+    }
+    else
+    {
+        moai::g_audit_blocks[a] = moai::AuditBlock{ bytes, stream, state == 2 };
+    }
+}
+
+extern "C" void moai_debug_stream_audit_counts(unsigned long long *checked, unsigned long long *violations)
+{
+    if (checked)
+    {
+        *checked = moai::g_audit_checked.load();
+    }
+    if (violations)
+    {
+        *violations = moai::g_audit_violations.load();
+    }
 }
 
 extern "C" int moai_version(void)
@@ -639,24 +737,28 @@ extern "C" int moai_free(void *dptr)
 
 extern "C" int moai_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
+    MOAI_AUDIT(stream, dst);
     MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return MOAI_OK;
 }
 
 extern "C" int moai_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
 {
+    MOAI_AUDIT(stream, src);
     MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return MOAI_OK;
 }
 
 extern "C" int moai_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
 {
+    MOAI_AUDIT(stream, dst, src);
     MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MOAI_OK;
 }
 
 extern "C" int moai_memset_zero(void *dst, size_t bytes, void *stream)
 {
+    MOAI_AUDIT(stream, dst);
     MOAI_HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream));
     return MOAI_OK;
 }

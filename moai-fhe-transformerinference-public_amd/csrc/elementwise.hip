@@ -817,6 +817,7 @@ using namespace moai;
 extern "C" int moai_add(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
                         void *stream)
 {
+    MOAI_AUDIT(stream, a, b, out);
     trace_op("add", L, n_poly);
     return ew_launch<EW_ADD>(c, a, b, out, n_poly, n_poly, L, stream);
 }
@@ -824,12 +825,14 @@ extern "C" int moai_add(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint6
 extern "C" int moai_sub(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly, size_t L,
                         void *stream)
 {
+    MOAI_AUDIT(stream, a, b, out);
     trace_op("sub", L, n_poly);
     return ew_launch<EW_SUB>(c, a, b, out, n_poly, n_poly, L, stream);
 }
 
 extern "C" int moai_negate(moai_ctx *c, const uint64_t *a, uint64_t *out, size_t n_poly, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, a, out);
     trace_op("negate", L, n_poly);
     return ew_launch<EW_NEG>(c, a, nullptr, out, n_poly, n_poly, L, stream);
 }
@@ -837,6 +840,7 @@ extern "C" int moai_negate(moai_ctx *c, const uint64_t *a, uint64_t *out, size_t
 extern "C" int moai_dyadic_mul(moai_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n_poly,
                                size_t n_poly_b, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, a, b, out);
     trace_op("dyadic_mul", L, n_poly);
     if (n_poly_b != n_poly && n_poly_b != 1)
     {
@@ -891,6 +895,7 @@ static int scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, 
 extern "C" int moai_mul_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
                                     size_t n_poly, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, a, scalars, out);
     trace_op("mul_scalar_rows", L, n_poly);
     return scalar_rows(c, a, scalars, out, n_poly, L, stream, true);
 }
@@ -898,6 +903,7 @@ extern "C" int moai_mul_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64
 extern "C" int moai_add_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,
                                     size_t n_poly, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, a, scalars, out);
     trace_op("add_scalar_rows", L, n_poly);
     return scalar_rows(c, a, scalars, out, n_poly, L, stream, false);
 }
@@ -946,12 +952,14 @@ static int ct_mul(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *o
 extern "C" int moai_ct_multiply(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t L,
                                 size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, x, y, out);
     trace_op("ct_multiply", L, batch);
     return ct_mul(c, x, y, out, L, batch, stream, false);
 }
 
 extern "C" int moai_ct_square(moai_ctx *c, const uint64_t *x, uint64_t *out, size_t L, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, x, out);
     trace_op("ct_square", L, batch);
     return ct_mul(c, x, x, out, L, batch, stream, true);
 }
@@ -959,6 +967,7 @@ extern "C" int moai_ct_square(moai_ctx *c, const uint64_t *x, uint64_t *out, siz
 extern "C" int moai_ct_multiply_general(moai_ctx *c, const uint64_t *x, size_t size_x, const uint64_t *y, size_t size_y,
                                         uint64_t *out, size_t L, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, x, y, out);
     trace_op("ct_multiply_general", L, batch);
     if (size_x < 2 || size_y < 2 || size_x > 16 || size_y > 16 || size_x + size_y - 1 > 16)
     {
@@ -1001,6 +1010,7 @@ extern "C" int moai_ct_multiply_general(moai_ctx *c, const uint64_t *x, size_t s
 extern "C" int moai_ct_dot(moai_ctx *c, const uint64_t *x, const uint64_t *y, uint64_t *out, size_t count, size_t L,
                            void *stream)
 {
+    MOAI_AUDIT(stream, x, y, out);
     trace_op("ct_dot", L, count);
     int rc = check_rows(c, count * 2, L);
     if (rc)
@@ -1118,6 +1128,7 @@ static int ct_pt_dot_common(moai_ctx *c, const uint64_t *x, const uint64_t *p, u
 extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
                               const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, x, p, out);
     trace_op("ct_pt_dot", L, n_poly * terms);
     return ct_pt_dot_common(c, x, p, out, nullptr, x_index, p_index, nullptr, terms, 0, n_poly, L, stream);
 }
@@ -1126,6 +1137,7 @@ extern "C" int moai_ct_pt_dot2(moai_ctx *c, const uint64_t *x, const uint64_t *p
                                const uint32_t *x_index, const uint32_t *p_index, const uint32_t *p_index2, size_t terms, size_t terms2,
                                size_t n_poly, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, x, p, out, out2);
     trace_op("ct_pt_dot", L, n_poly * (terms + terms2)); // the same products as two moai_ct_pt_dot calls
     if (!out2)
     {
@@ -1137,6 +1149,7 @@ extern "C" int moai_ct_pt_dot2(moai_ctx *c, const uint64_t *x, const uint64_t *p
 extern "C" int moai_ct_pt_dot_rows(moai_ctx *c, const uint64_t *x, const uint64_t *p, const uint64_t *p2, uint64_t *out, uint64_t *out2,
                                    size_t rows, size_t n_poly, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, x, p, p2, out, out2);
     trace_op("ct_pt_dot", L, n_poly * rows * (p2 ? 2 : 1)); // the products of moai_ct_pt_dot calls over the same rows
     int rc = check_rows(c, n_poly, L);
     if (rc)
@@ -1206,6 +1219,7 @@ extern "C" int moai_ct_pt_dot_rows(moai_ctx *c, const uint64_t *x, const uint64_
 extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t drop,
                              size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, out);
     trace_op("mod_drop", L, batch * size);
     int rc = check_rows(c, batch * size, L);
     if (rc)
@@ -1244,6 +1258,7 @@ extern "C" int moai_mod_drop(moai_ctx *c, const uint64_t *in, uint64_t *out, siz
 extern "C" int moai_galois_permute(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t n_poly, size_t L,
                                    uint32_t galois_elt, void *stream)
 {
+    MOAI_AUDIT(stream, in, out);
     trace_op("galois_permute", L, n_poly);
     int rc = check_rows(c, n_poly, L);
     if (rc)
@@ -1326,6 +1341,7 @@ extern "C" uint32_t moai_galois_elt_from_step(const moai_ctx *c, int step)
 extern "C" int moai_ct_pt_matmul(moai_ctx *c, const uint64_t *x, const uint64_t *w, uint64_t *out, size_t rows,
                                  size_t cols, size_t size, size_t L, void *stream)
 {
+    MOAI_AUDIT(stream, x, w, out);
     trace_op("ct_pt_matmul", L, rows * cols * size);
     int rc = check_rows(c, (rows > cols ? rows : cols) * size, L);
     if (rc)

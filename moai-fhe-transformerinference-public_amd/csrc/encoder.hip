@@ -723,6 +723,7 @@ extern "C" int moai_ckks_encode(moai_ctx *c, const double *values, int is_comple
                                 size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index, double scale,
                                 double *max_coeff, void *stream)
 {
+    MOAI_AUDIT(stream, dst, values, max_coeff);
     trace_op("ckks_encode", L, n_batch);
     return encode_impl(c, values, nullptr, is_complex, values_size, n_batch, dst, L, prime_index, scale, max_coeff, stream);
 }
@@ -731,6 +732,7 @@ extern "C" int moai_ckks_encode_masked(moai_ctx *c, const double *constants, con
                                        size_t n_batch, uint64_t *dst, size_t L, const uint32_t *prime_index,
                                        double scale, double *max_coeff, void *stream)
 {
+    MOAI_AUDIT(stream, dst, constants, mask, max_coeff);
     trace_op("ckks_encode_masked", L, n_batch);
     if (!mask && mask_size > 0)
     {

@@ -848,6 +848,7 @@ static int rescale_common(moai_ctx *c, const uint64_t *in, const uint64_t *scala
 extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t size, size_t L, size_t batch,
                             void *stream)
 {
+    MOAI_AUDIT(stream, in, out);
     trace_op("rescale", L, batch * size);
     return rescale_common(c, in, nullptr, nullptr, out, size, L, batch, stream);
 }
@@ -855,6 +856,7 @@ extern "C" int moai_rescale(moai_ctx *c, const uint64_t *in, uint64_t *out, size
 extern "C" int moai_rescale_add(moai_ctx *c, const uint64_t *in, const uint64_t *addend, uint64_t *out, size_t size, size_t L,
                                 size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, addend, out);
     trace_op("rescale_add", L, batch * size);
     if (!addend)
     {
@@ -866,6 +868,7 @@ extern "C" int moai_rescale_add(moai_ctx *c, const uint64_t *in, const uint64_t 
 extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, uint64_t *out, size_t size,
                                        size_t L, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, scalars, out);
     trace_op("mul_scalar_rescale", L, batch * size);
     if (!scalars)
     {
@@ -877,6 +880,7 @@ extern "C" int moai_mul_scalar_rescale(moai_ctx *c, const uint64_t *in, const ui
 extern "C" int moai_mul_scalar_rescale_add(moai_ctx *c, const uint64_t *in, const uint64_t *scalars, const uint64_t *addend,
                                            uint64_t *out, size_t size, size_t L, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, scalars, addend, out);
     trace_op("mul_scalar_rescale_add", L, batch * size);
     if (!scalars || !addend)
     {
@@ -888,6 +892,7 @@ extern "C" int moai_mul_scalar_rescale_add(moai_ctx *c, const uint64_t *in, cons
 extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t L,
                                size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, ct, target, key);
     trace_op("switch_key", L, batch);
     int rc = check_level(c, L, batch * 2);
     if (rc)
@@ -915,6 +920,7 @@ extern "C" int moai_switch_key(moai_ctx *c, uint64_t *ct, const uint64_t *target
 extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t *relin_key, uint64_t *out, size_t L,
                                 size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, ct3, relin_key, out);
     trace_op("relinearize", L, batch);
     int rc = check_level(c, L, batch * 3);
     if (rc)
@@ -945,6 +951,7 @@ extern "C" int moai_relinearize(moai_ctx *c, const uint64_t *ct3, const uint64_t
 extern "C" int moai_apply_galois_to(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L, uint32_t galois_elt,
                                     const uint64_t *galois_key, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, out, galois_key);
     trace_op("apply_galois_to", L, batch);
     int rc = check_level(c, L, batch * 2);
     if (rc)
@@ -984,12 +991,14 @@ extern "C" int moai_apply_galois_to(moai_ctx *c, const uint64_t *in, uint64_t *o
 extern "C" int moai_apply_galois(moai_ctx *c, uint64_t *ct, size_t L, uint32_t galois_elt, const uint64_t *galois_key,
                                  size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, ct, galois_key);
     return moai_apply_galois_to(c, ct, ct, L, galois_elt, galois_key, batch, stream);
 }
 
 extern "C" int moai_apply_galois_acc(moai_ctx *c, const uint64_t *in, uint64_t *acc, size_t L, uint32_t galois_elt,
                                      const uint64_t *galois_key, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, acc, galois_key);
     trace_op("apply_galois_to", L, batch); // the same key switch; the addition that follows it is what is saved
     int rc = check_level(c, L, batch * 2);
     if (rc)
@@ -1027,6 +1036,7 @@ extern "C" int moai_apply_galois_acc(moai_ctx *c, const uint64_t *in, uint64_t *
 
 extern "C" int moai_modraise(moai_ctx *c, const uint64_t *in, uint64_t *out, size_t L_out, size_t batch, void *stream)
 {
+    MOAI_AUDIT(stream, in, out);
     trace_op("modraise", L_out, batch);
     const size_t P = batch * 2;
     int rc = check_level(c, L_out, P);
@@ -1227,6 +1237,7 @@ static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint
 extern "C" int moai_hoist_correction(moai_ctx *c, const uint64_t *galois_key, uint32_t galois_elt, size_t L, uint64_t *correction,
                                      void *stream)
 {
+    MOAI_AUDIT(stream, galois_key, correction);
     trace_op("hoist_correction", L, 1);
     int rc = check_level(c, L, 2);
     if (rc)
@@ -1293,6 +1304,33 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
                                          const uint64_t *const *galois_keys, const uint64_t *const *corrections, size_t R, size_t batch,
                                          int *used_fallback, void *stream)
 {
+    MOAI_AUDIT(stream, in);
+    for (size_t r = 0; outs && galois_keys && corrections && r < R; ++r)
+    {
+        MOAI_AUDIT(stream, outs[r], galois_keys[r], corrections[r]);
+    }
+    if (R > 64 && outs && galois_elts && galois_keys && corrections)
+    {
+        // the accumulators of one pass are sized for 64 rotations: more are done 64 at a time, each pass with its own digit
+        // decomposition (the results do not depend on the grouping)
+        int any_fallback = 0;
+        for (size_t r0 = 0; r0 < R; r0 += 64)
+        {
+            int fb = 0;
+            const int rc = moai_apply_galois_hoisted(c, in, outs + r0, L, galois_elts + r0, galois_keys + r0, corrections + r0,
+                                                     R - r0 < 64 ? R - r0 : 64, batch, &fb, stream);
+            if (rc)
+            {
+                return rc;
+            }
+            any_fallback |= fb;
+        }
+        if (used_fallback)
+        {
+            *used_fallback = any_fallback;
+        }
+        return MOAI_OK;
+    }
     trace_op("apply_galois_hoisted", L, batch * R);
     if (used_fallback)
     {
@@ -1319,10 +1357,6 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
     if (L > k - 1)
     {
         return set_error(MOAI_EINVAL, "L exceeds the key's decomposition size");
-    }
-    if (R > 64)
-    {
-        return set_error(MOAI_EINVAL, "at most 64 rotations per call");
     }
     hipStream_t s = (hipStream_t)stream;
     std::vector<const uint32_t *> tables(R), itables(R);

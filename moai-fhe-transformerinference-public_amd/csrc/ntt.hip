@@ -401,6 +401,7 @@ static int ntt_entry(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const
 extern "C" int moai_ntt_forward(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
                                 void *stream)
 {
+    MOAI_AUDIT(stream, data);
     trace_op("ntt_forward", L, n_poly);
     return ntt_entry(c, data, n_poly, L, prime_index, stream, false);
 }
@@ -408,6 +409,7 @@ extern "C" int moai_ntt_forward(moai_ctx *c, uint64_t *data, size_t n_poly, size
 extern "C" int moai_ntt_inverse(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const uint32_t *prime_index,
                                 void *stream)
 {
+    MOAI_AUDIT(stream, data);
     trace_op("ntt_inverse", L, n_poly);
     return ntt_entry(c, data, n_poly, L, prime_index, stream, true);
 }

@@ -76,6 +76,9 @@ SYMBOLS = {
     "moai_mem_info": (C.c_int, [C.POINTER(sz), C.POINTER(sz)]),
     "moai_op_trace": (C.c_int, [C.c_int]),
     "moai_op_trace_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "moai_debug_stream_audit": (C.c_int, [C.c_int]),
+    "moai_debug_block_label": (None, [vp, sz, vp, C.c_int]),
+    "moai_debug_stream_audit_counts": (None, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "moai_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
     "moai_event_create": (C.c_int, [C.POINTER(vp)]),
     "moai_event_destroy": (C.c_int, [vp]),

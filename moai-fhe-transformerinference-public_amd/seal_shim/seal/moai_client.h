@@ -727,6 +727,7 @@ namespace seal
             util::hip_check(moai_dyadic_mul(context_.device(), sk_.ntt_->get(), sk_.ntt_->get(), s2.get(), 1, 1, k_,
                                             context_.stream()));
             destination.keys_.assign(1, nullptr);
+            destination.hoist_ = std::make_shared<KSwitchKeys::HoistCache>(); // constants derived from the keys this call replaces
             destination.keys_[0] = make_kswitch_key(s2.get());
             destination.parms_id_ = context_.key_parms_id();
             context_.sync();
@@ -739,6 +740,10 @@ namespace seal
                 throw std::logic_error("keyswitching is not supported by the context");
             }
             destination.keys_.assign(n_, nullptr);
+            // the hoisted-rotation constants are functions of the key (KSwitchKeys::hoist_correction): regenerating keys into an
+            // object that already served hoisted rotations must not leave the old keys' constants behind.  A copy made earlier
+            // keeps the old keys together with the old cache; copies made from now on share the new one.
+            destination.hoist_ = std::make_shared<KSwitchKeys::HoistCache>();
             util::DeviceArray rotated(k_ * n_, context_.stream());
             for (std::uint32_t elt : galois_elts)
             {

@@ -234,6 +234,11 @@ namespace seal
         // SEAL/util/mempool.h:228).  A released block may be handed to a later request of the same size on the
         // SAME stream only: everything that touched it was enqueued on that stream before the release, so stream
         // order makes the reuse safe without synchronising, and hipFree's implicit device sync is avoided.
+        // That invariant -- a block is only ever handed to the library together with the stream it is labelled with -- is
+        // enforced by construction where it can be (a DeviceArray cannot be allocated without a stream; every shim object
+        // takes SEALContext::stream()) and CHECKED under MOAI_STREAM_AUDIT=1: the pool reports every block's label and
+        // state to the library (moai_debug_block_label), and every entry point that enqueues work refuses a pointer whose
+        // block carries another stream's label or has been released (include/moai_hip.h, "stream audit").
         class DevicePool
         {
         public:
@@ -276,6 +281,7 @@ namespace seal
                             {
                                 *granted = it->first.second;
                             }
+                            label(p, it->first.second, stream, 1);
                             return p;
                         }
                         ++it;
@@ -314,15 +320,18 @@ namespace seal
                         rc = moai_malloc(&p, bytes);
                     }
                 }
+                label(p, bytes, stream, 1);
                 return p;
             }
             void release(void *p, std::size_t bytes, void *stream)
             {
                 if (bytes > cap_)
                 {
+                    label(p, bytes, stream, 0);
                     moai_free(p); // larger than the whole cache may be (MOAI_POOL_CACHE_MB=0 switches caching off)
                     return;
                 }
+                label(p, bytes, stream, 2);
                 bool full;
                 {
                     std::lock_guard<std::mutex> g(mu_);
@@ -412,6 +421,7 @@ namespace seal
                 const auto t0 = std::chrono::steady_clock::now();
                 for (void *p : victims)
                 {
+                    label(p, 0, nullptr, 0);
                     moai_free(p);
                 }
                 if (std::getenv("MOAI_POOL_DEBUG"))
@@ -441,6 +451,18 @@ namespace seal
             ~DevicePool() = default;
 
         private:
+            // stream audit (debug): tell the library which stream a block belongs to; 1 = in use, 2 = cached, 0 = gone
+            static void label(void *p, std::size_t bytes, void *stream, int state)
+            {
+                static const bool audit = [] {
+                    const char *e = std::getenv("MOAI_STREAM_AUDIT");
+                    return e && e[0] != '0';
+                }();
+                if (audit)
+                {
+                    moai_debug_block_label(p, bytes, stream, state);
+                }
+            }
             DevicePool()
             {
                 const char *e = std::getenv("MOAI_POOL_CACHE_MB");
@@ -464,7 +486,8 @@ namespace seal
         {
         public:
             DeviceArray() = default;
-            explicit DeviceArray(std::size_t words, void *stream = nullptr)
+            // no default for the stream: the pool's reuse rule rests on the label being the stream the block is used on
+            DeviceArray(std::size_t words, void *stream)
             {
                 resize(words, stream);
             }
@@ -503,12 +526,18 @@ namespace seal
                 words_ = cap_ = 0;
             }
             // keeps the leading words (like DynArray::resize, SEAL/dynarray.h)
-            void resize(std::size_t words, void *stream = nullptr)
+            void resize(std::size_t words, void *stream)
             {
                 if (words <= cap_)
                 {
                     words_ = words;
                     return;
+                }
+                if (!stream)
+                {
+                    // the legacy stream does not order against a context's non-blocking stream: a block labelled with it would
+                    // be recycled without any ordering against the kernels that use it
+                    throw std::logic_error("DeviceArray: a device block needs the stream it will be used on");
                 }
                 std::size_t alloc_words = DevicePool::size_class(words * sizeof(std::uint64_t)) / sizeof(std::uint64_t);
                 std::size_t granted = 0;

@@ -649,6 +649,68 @@ static void device_pool()
     CHECK(pool.trim() == big);
 }
 
+// Keys regenerated into an object that already served hoisted rotations (legal SEAL usage: KeyGenerator::create_galois_keys
+// overwrites its destination).  The per-(key, level) constant of a hoisted rotation is cached in the key object
+// (KSwitchKeys::hoist_correction); it is a function of the key's bits, so the new keys must not find the old keys' constants.
+static void regenerated_keys_and_hoisting()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    const size_t N = 4096;
+    parms.set_poly_modulus_degree(N);
+    parms.set_coeff_modulus(CoeffModulus::Create(N, { 51, 46, 46, 58 }));
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    Encryptor encryptor(context, pk);
+    CKKSEncoder encoder(context);
+    Evaluator evaluator(context, encoder);
+    vector<double> v(encoder.slot_count());
+    for (size_t i = 0; i < v.size(); i++) v[i] = 0.001 * (double)(i % 97);
+    Plaintext p;
+    encoder.encode(v, pow(2.0, 40), p);
+    Ciphertext ct;
+    encryptor.encrypt(p, ct);
+    const size_t L = ct.coeff_modulus_size();
+    const vector<int> steps = { 1, 2, 5 };
+    GaloisKeys gk;
+    auto hoisted_equals_separate = [&](const GaloisKeys &keys) {
+        vector<Ciphertext> hoisted(steps.size());
+        vector<uint32_t> elts;
+        vector<const uint64_t *> kptr, cptr;
+        vector<uint64_t *> optr;
+        for (size_t r = 0; r < steps.size(); r++)
+        {
+            hoisted[r].resize(context, ct.parms_id(), 2);
+            const uint32_t e = moai_galois_elt_from_step(context.device(), steps[r]);
+            elts.push_back(e);
+            kptr.push_back(keys.device_key(GaloisKeys::get_index(e)));
+            cptr.push_back(keys.hoist_correction(context, GaloisKeys::get_index(e), e, L));
+            optr.push_back(hoisted[r].device_data());
+        }
+        int fell_back = 0;
+        util::hip_check(moai_apply_galois_hoisted(context.device(), ct.device_data(), optr.data(), L, elts.data(), kptr.data(), cptr.data(),
+                                                  steps.size(), 1, &fell_back, context.stream()));
+        CHECK(!fell_back);
+        bool same = true;
+        for (size_t r = 0; r < steps.size(); r++)
+        {
+            Ciphertext separate;
+            evaluator.rotate_vector(ct, steps[r], keys, separate);
+            same = same && separate.download() == hoisted[r].download();
+        }
+        return same;
+    };
+    keygen.create_galois_keys(steps, gk);
+    CHECK(hoisted_equals_separate(gk));
+    GaloisKeys earlier_copy = gk; // keeps the first keys AND their constants
+    keygen.create_galois_keys(steps, gk); // fresh randomness: other key bits for the same secret
+    CHECK(hoisted_equals_separate(gk));
+    CHECK(hoisted_equals_separate(earlier_copy));
+    GaloisKeys later_copy = gk;
+    CHECK(hoisted_equals_separate(later_copy));
+}
+
 int main()
 {
     try
@@ -658,6 +720,7 @@ int main()
         evaluator_ops();
         concurrent_callers();
         packed_random_program();
+        regenerated_keys_and_hoisting();
     }
     catch (const std::exception &e)
     {

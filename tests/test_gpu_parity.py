@@ -889,3 +889,85 @@ def test_hoisted_rotations_equal_separate_rotations(moai, logn, bits, L, B, ks_a
     got = dout.to_numpy((len(steps), B, 2, L, n))
     for r, (e, kk) in enumerate(zip(elts, keys)):
         assert (got[r, 0] == octx.apply_galois(ct0[0], L, e, kk).reshape(2, L, n)).all(), r
+
+
+@pytest.mark.gpu
+def test_hoisted_rotations_more_than_one_pass_holds(moai):
+    """R = 65 rotations of one ciphertext in one moai_apply_galois_hoisted call: the accumulators of a pass hold 64, so the
+    call makes two passes (a GaloisKeys with a dedicated key per step hands MOAI's Q K^T loop 127 children of one node,
+    Ct_ct_matrix_mul.hpp:22-31); every rotation against the oracle's apply_galois, bit for bit."""
+    logn, bits, L, B = 12, [46, 46, 58], 2, 1
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k = len(primes)
+    rng = np.random.default_rng(65)
+    steps = list(range(1, 66))
+    elts = [ctx.galois_elt_from_step(s) for s in steps]
+    # two distinct keys, shared round-robin (the call takes one pointer per rotation; 65 uploads would only cost time)
+    keys = [O.uniform_rns(rng, primes, (k - 1, 2), n) for _ in range(2)]
+    dkeys2 = [up(moai, kk) for kk in keys]
+    dkeys = [dkeys2[r % 2] for r in range(len(steps))]
+    corrs = [ctx.hoist_correction(dkeys[r], elts[r], L) for r in range(len(steps))]
+    ct = O.uniform_rns(rng, primes[:L], (B, 2), n)
+    dct = up(moai, ct)
+    dout = moai.DeviceBuffer(len(steps) * B * 2 * L * n)
+    assert not ctx.apply_galois_hoisted(dct, dout, L, elts, dkeys, corrs, B)
+    got = dout.to_numpy((len(steps), B, 2, L, n))
+    for r in (0, 1, 31, 63, 64):
+        assert (got[r, 0] == octx.apply_galois(ct[0], L, elts[r], keys[r % 2]).reshape(2, L, n)).all(), r
+    # and all 65 against the single-rotation entry point of the same library
+    for r in range(len(steps)):
+        d1 = up(moai, ct)
+        ctx.apply_galois(d1, L, elts[r], dkeys[r], B)
+        assert (d1.to_numpy(ct.shape)[0] == got[r, 0]).all(), r
+
+
+@pytest.mark.gpu
+def test_stream_audit_refuses_a_block_on_another_stream(moai):
+    """The debug audit behind the shim's stream-ordered block cache (include/moai_hip.h, "stream audit"): a labelled block
+    is accepted on its own stream, refused (MOAI_ELOGIC, before anything is enqueued) on any other stream and after it was
+    released to the cache; unlabelled memory is never refused."""
+    import ctypes as C
+
+    L = moai.hip.lib()
+    logn, primes = 10, O.coeff_modulus_create(1 << 10, [46, 46])
+    ctx = moai.Context(logn, primes)
+    n = 1 << logn
+    rng = np.random.default_rng(3)
+    a = O.uniform_rns(rng, primes, (1,), n)
+    da, db, dout = up(moai, a), up(moai, a), moai.DeviceBuffer(2 * n)
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    assert L.moai_stream_create(C.byref(s1)) == 0 and L.moai_stream_create(C.byref(s2)) == 0
+    was = L.moai_debug_stream_audit(1)
+    try:
+        ctx.add(da, db, dout, 1, 2, stream=s1)  # nothing labelled: accepted
+        L.moai_debug_block_label(da.ptr, 2 * n * 8, s1, 1)
+        ctx.add(da, db, dout, 1, 2, stream=s1)  # on its own stream
+        with pytest.raises(moai.hip.MoaiError) as e:
+            ctx.add(da, db, dout, 1, 2, stream=s2)
+        assert e.value.code == -2 and "stream audit" in str(e.value)
+        with pytest.raises(moai.hip.MoaiError):
+            ctx.add(db, da, dout, 1, 2, stream=None)  # the legacy stream is another stream, too
+        with pytest.raises(moai.hip.MoaiError):  # a pointer INSIDE the block
+            L_rc = L.moai_memcpy_d2d(dout.ptr, da.ptr + 64, 64, s2)
+            moai.hip._check(L_rc)
+        L.moai_debug_block_label(da.ptr, 2 * n * 8, s1, 2)  # released to the cache of s1
+        with pytest.raises(moai.hip.MoaiError) as e:
+            ctx.add(da, db, dout, 1, 2, stream=s1)
+        assert "released" in str(e.value)
+        L.moai_debug_block_label(da.ptr, 0, None, 0)  # forgotten
+        ctx.add(da, db, dout, 1, 2, stream=s2)
+        L.moai_stream_sync(s1)
+        L.moai_stream_sync(s2)
+        assert (dout.to_numpy((1, 2, n)) == octx_add(primes, a)).all()
+    finally:
+        L.moai_debug_block_label(da.ptr, 0, None, 0)
+        L.moai_debug_stream_audit(was)
+        L.moai_stream_destroy(s1)
+        L.moai_stream_destroy(s2)
+
+
+def octx_add(primes, a):
+    q = np.array(primes, dtype=np.uint64)[None, :, None]
+    return (a + a) % q

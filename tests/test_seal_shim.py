@@ -83,10 +83,13 @@ def test_bootstrap_setup_constants_host_checks():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("binary", ["test_seal_shim", "test_moai_headers", "test_moai_attention", "test_bootstrap_lt", "test_bootstrap_eval",
-                                    "test_bootstrap_real"])
+                                    "test_bootstrap_real", "test_moai_drivers", "test_moai_fixtures"])
 def test_cpp_binary_passes_on_gpu(binary):
     """test_moai_headers / test_moai_attention include MOAI's own headers from the reference checkout at build time (the
-    binaries travel prebuilt); test_moai_attention is MOAI's single_att_block + softmax_boot unchanged, checked by decryption"""
+    binaries travel prebuilt); test_moai_attention is MOAI's single_att_block + softmax_boot unchanged, checked by decryption;
+    test_moai_drivers = the three weight-free drivers the reference's test.cpp:18-30 calls, through its include.hpp, printed slots
+    asserted against their closed forms; test_moai_fixtures = MOAI's Q K^T / softmax_boot / . V / layernorm / layernorm2 /
+    gelu_v2 at N = 2^16 on the 36-prime chain against the reference's own activation fixtures (tests/golden/moai_data)"""
     if binary.startswith("test_moai_") and not os.path.exists(os.path.join(CPP, binary)) and not os.path.isdir(REF):
         pytest.skip("built from MOAI's own headers, which only the build container holds")
     r = subprocess.run([os.path.join(CPP, binary)], cwd=CPP, capture_output=True, text=True, timeout=600)

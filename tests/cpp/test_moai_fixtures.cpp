@@ -253,8 +253,45 @@ int main(int argc, char **argv)
     };
     const double q0 = Qp[0];
     const double r = scale / q0, slope = bootstrapper.mod_reducer->inverse_sin_polynomial.chebcoeff[1];
-    // what bootstrap_3 returns for a slot value m that entered at scale 2^46 on the last prime: index 20, scale 2^46
-    auto boot_transfer = [&](double m) { return CV{ slope * sin(2 * M_PI * r * m) / r, scale, remaining_level + 1 }; };
+    // bootstrap_3 in the clear.  The modular reduction acts on the COEFFICIENTS of the plaintext polynomial, not on its slots
+    // (coefficient-to-slot, the approximate  a sin(2 pi t / q0)  on every coefficient t, slot-to-coefficient; Bootstrapper.cpp:
+    // 3231-3251): for slots z_p (real, at the roots zeta^(5^p) of the encoder, SEAL/ckks.cpp:36-52) plus a constant c0 in
+    // every slot, c_j = (2 / N) sum_p z_p cos(pi e_p j / N), each c_j goes through  a sin(2 pi r c) / r  with r = scale / q0,
+    // and the slots are evaluated again.  With a few non-zero slots the coefficients are ~1e-3 of the slot values, so the sine
+    // is deep in its linear part although a slot (a sum of exponentials up to 1.2) is far outside the +-2^-10 q0 / scale
+    // where a coefficient is meant to lie.  Returns the values at the same slots; result at index 20, scale 2^46.
+    auto emu_bootstrap = [&](const vector<size_t> &slots, const vector<double> &z, double c0) {
+        const size_t N = poly_modulus_degree, M = 2 * N;
+        vector<size_t> e(slots.size());
+        for (size_t i = 0; i < slots.size(); i++)
+        {
+            size_t pos = 1;
+            for (size_t t = 0; t < slots[i]; t++) pos = pos * 5 % M; // 5^slot mod 2N
+            e[i] = pos;
+        }
+        vector<double> costab(M);
+        for (size_t a = 0; a < M; a++) costab[a] = cos(M_PI * (double)a / (double)N);
+        vector<double> c(N, 0.0);
+        for (size_t i = 0; i < slots.size(); i++)
+            for (size_t j = 0; j < N; j++) c[j] += 2.0 / (double)N * z[i] * costab[e[i] * j % M];
+        c[0] += c0;
+        double cmax = 0;
+        for (size_t j = 0; j < N; j++)
+        {
+            cmax = max(cmax, fabs(c[j]));
+            c[j] = slope * sin(2 * M_PI * r * c[j]) / r;
+        }
+        vector<CV> out(slots.size());
+        for (size_t i = 0; i < slots.size(); i++)
+        {
+            double v = 0;
+            for (size_t j = 0; j < N; j++) v += c[j] * costab[e[i] * j % M];
+            out[i] = CV{ v, scale, remaining_level + 1 };
+        }
+        printf("          bootstrap in the clear: largest coefficient %.2e of the scale (the reduction is built for +-%.2e)\n", cmax,
+               pow(2.0, -(double)loge) / r);
+        return out;
+    };
     auto emu_exp = [&](CV x) { // softmax.hpp:9-47
         CV out = rescale(mulp(x, 0.0078125, x.s));
         out.v += 1.0;
@@ -453,30 +490,40 @@ int main(int argc, char **argv)
             Mat sm_model(num_head * input_num, vector<double>(input_num));
             vector<double> row_sum(num_head * input_num);
             double sum_max = 0, sum_min = 1e9, score_max = -1e9, inv_drift = 0;
+            vector<vector<CV>> e_all(num_head * input_num, vector<CV>(input_num));
+            vector<size_t> boot_slots;
+            vector<double> boot_in;
             for (int h = 0; h < num_head; h++)
                 for (int k = 0; k < input_num; k++)
                 {
                     // softmax.hpp:330-466: shift, exp, mask (a plaintext of ones at the running scale), scale overwritten
-                    vector<CV> e(input_num);
-                    CV sum{ 0.00001, scale, 0 }; // :514: + 0.00001
+                    vector<CV> &e = e_all[h * input_num + k];
+                    double sum = 0;
                     for (int k2 = 0; k2 < input_num; k2++)
                     {
                         score_max = max(score_max, score[h * input_num + k][k2]);
                         CV x = emu_exp(CV{ score[h * input_num + k][k2] - minus_index, scale, 14 });
                         e[k2] = force(rescale(mulp(x, 1.0, x.s)), scale);
-                        sum.v += e[k2].v;
-                        sum.L = e[k2].L;
+                        sum += e[k2].v;
                     }
-                    sum_max = max(sum_max, sum.v);
-                    row_sum[h * input_num + k] = sum.v;
-                    sum_min = min(sum_min, sum.v);
-                    // :533-545: bootstrap, switch down to index iter + 4, reciprocal, scale overwritten
-                    const CV raw = emu_inverse(to_level(boot_transfer(sum.v), iter + 1 + 3 + 1));
+                    boot_slots.push_back((size_t)num_X * k + h);
+                    boot_in.push_back(sum);
+                    sum += 0.00001; // :514, a scalar plaintext: the same constant in every slot
+                    sum_max = max(sum_max, sum);
+                    row_sum[h * input_num + k] = sum;
+                    sum_min = min(sum_min, sum);
+                }
+            // :533-545: bootstrap, switch down to index iter + 4, reciprocal, scale overwritten
+            const vector<CV> booted = emu_bootstrap(boot_slots, boot_in, 0.00001);
+            for (int h = 0; h < num_head; h++)
+                for (int k = 0; k < input_num; k++)
+                {
+                    const CV raw = emu_inverse(to_level(booted[h * input_num + k], iter + 1 + 3 + 1));
                     inv_drift = max(inv_drift, fabs(raw.s / scale - 1));
                     const CV inv = force(raw, scale);
                     // :566-575
                     for (int k2 = 0; k2 < input_num; k2++)
-                        sm_model[h * input_num + k][k2] = force(rescale(mul(to_level(e[k2], inv.L), inv)), scale).v;
+                        sm_model[h * input_num + k][k2] = force(rescale(mul(to_level(e_all[h * input_num + k][k2], inv.L), inv)), scale).v;
                 }
             printf("layer %2d  sums of exponentials in [%.4f, %.3f]; overwriting the reciprocal's scale changes it by %.2e of its value\n", layer,
                    sum_min, sum_max, inv_drift);

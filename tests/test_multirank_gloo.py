@@ -32,8 +32,13 @@ def _worker(rank, world, port, q):
     weak = bench.batch_of_rank(256, rank, world, False, m.shard)
     job_split = m.shard.sum_over_ranks(float(split[0]), dist)
     job_weak = m.shard.sum_over_ranks(float(weak[0]), dist)
+    # the end-to-end replicas of `bench.py --gpus 2`: each rank measured its own encoder layer (rank 1's GPU was slower); the
+    # job's inputs per second are summed, no exchange step
+    agg = m.shard.aggregate_replicas(200.0 if rank == 0 else 250.0, 256, 12, dist)
+    # ... and when one replica fails the others still count
+    agg_partial = m.shard.aggregate_replicas(None if rank == 1 else 200.0, 256, 12, dist)
     m.shard.barrier(dist)
-    q.put((rank, start, count, t, rate, split, weak, job_split, job_weak))
+    q.put((rank, start, count, t, rate, split, weak, job_split, job_weak, agg, agg_partial))
     dist.destroy_process_group()
 
 
@@ -50,7 +55,14 @@ def test_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, c0, t0, rate0, split0, weak0, js0, jw0), (r1, s1, c1, t1, rate1, split1, weak1, js1, jw1) = res
+    (r0, s0, c0, t0, rate0, split0, weak0, js0, jw0, agg0, part0), (r1, s1, c1, t1, rate1, split1, weak1, js1, jw1, agg1, part1) = res
+    # replicas: 256 / (12 x 200) + 256 / (12 x 250) inputs per second, the same figure on both ranks
+    assert agg0 == agg1 and agg0["n_gpus"] == 2 and agg0["replicas_completed"] == 2
+    assert agg0["inputs_per_s"] == pytest.approx(256 / 2400.0 + 256 / 3000.0)
+    assert agg0["ms_per_input"] == pytest.approx(1e3 / (256 / 2400.0 + 256 / 3000.0))
+    assert agg0["layer_s_slowest"] == 250.0 and agg0["layer_s_fastest"] == 200.0
+    assert part0 == part1 and part0["replicas_completed"] == 1 and part0["inputs_per_s"] == pytest.approx(256 / 2400.0)
+    assert part0["layer_s_slowest"] == part0["layer_s_fastest"] == 200.0
     # --split: rank 0 transforms ciphertexts [0, 128), rank 1 [128, 256) of the ONE batch; without it 256 each
     assert split0 == (128, 0) and split1 == (128, 128)
     assert weak0 == (256, 0) and weak1 == (256, 256)
@@ -74,3 +86,23 @@ def test_shard_range_properties():
             assert cover == list(range(total))
     with pytest.raises(ValueError):
         m.shard.shard_range(8, 2, 2)
+
+
+def test_replica_child_is_bound_to_the_ranks_device():
+    """bench.py --gpus N starts one end-to-end child per rank; the child must see the rank's GPU as its only device, whatever
+    the launcher already restricted."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+
+    m = g.load_package()
+    env = m.shard.replica_env(3, {"PATH": "/bin"})
+    assert env["HIP_VISIBLE_DEVICES"] == "3" and env["PATH"] == "/bin" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    env = m.shard.replica_env(1, {"HIP_VISIBLE_DEVICES": "4,6,7"})
+    assert env["HIP_VISIBLE_DEVICES"] == "6"
+    env = m.shard.replica_env(0, {"CUDA_VISIBLE_DEVICES": "5", "HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert env["HIP_VISIBLE_DEVICES"] == "5" and "CUDA_VISIBLE_DEVICES" not in env and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    with pytest.raises(ValueError):
+        m.shard.replica_env(2, {"HIP_VISIBLE_DEVICES": "0,1"})
+    # one replica, no process group: the rank's own figures
+    agg = m.shard.aggregate_replicas(192.0, 256, 12, None)
+    assert agg["n_gpus"] == 1 and agg["replicas_completed"] == 1 and agg["ms_per_input"] == pytest.approx(12 * 192.0 / 256 * 1e3)

@@ -5,7 +5,14 @@
 //      call from an OpenMP loop (test_full_scheme.hpp:654-660), which the drop-in Bootstrapper gathers into packed runs;
 //   2. one attention head through MOAI's OWN single_att_block.hpp / softmax.hpp / matrix-product headers, unchanged
 //      (included from the reference checkout at build time; the binary travels prebuilt), on 768 input ciphertexts
-//      carrying 256 packed inputs, with the decrypted result checked against the attention computed in the clear.
+//      carrying 256 packed inputs, with the decrypted result checked against the attention computed in the clear;
+//   3. a SLICE of the feed-forward half through MOAI's own, unchanged loops (Ct_pt_matrix_mul.hpp, gelu_others.hpp): 128 of
+//      the 768 output columns of the self-output product (768 rows, masked vector weights, chain index 1), 128 of the 3072
+//      columns of the intermediate product (768 rows, scalar weights, index 9), 128 of the 768 columns of the final product
+//      (3072 rows, masked vector weights, index 1) and gelu_v2 on 128 of the 3072 ciphertexts (index 8), one call per
+//      ciphertext from the OpenMP loop of test_full_scheme.hpp:884-888.  Each routine's work is linear in its column count
+//      (its loop is `for 128 x (columns / 128)`), so bench.py scales the slice to the layer: what an UNCHANGED
+//      all_layer_test would cost here.  --no-ffn skips it.
 // Weights and inputs are synthetic (the reference's dense weights are not in its checkout, .MISSING_LARGE_BLOBS).
 // While each part runs, the library's operation census (moai_op_trace) records what the evaluator was asked to do per
 // level; bench.py prices those counts on the CPU oracle of the same host.  Last line: `E2E_JSON {...}`.
@@ -30,6 +37,7 @@
 #include "Ct_ct_matrix_mul.hpp"
 #include "softmax.hpp"
 #include "single_att_block.hpp"
+#include "gelu_others.hpp"
 
 static double now_s()
 {
@@ -86,7 +94,12 @@ int main(int argc, char **argv)
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const int pack = argc > 1 ? atoi(argv[1]) : 48;
     const int threads = argc > 2 ? atoi(argv[2]) : usable_threads();
-    const bool with_head = !(argc > 3 && !strcmp(argv[3], "--no-head"));
+    bool with_head = true, with_ffn = true;
+    for (int i = 3; i < argc; i++)
+    {
+        with_head = with_head && strcmp(argv[i], "--no-head");
+        with_ffn = with_ffn && strcmp(argv[i], "--no-ffn");
+    }
     omp_set_num_threads(threads);
     const double t_start = now_s();
 
@@ -315,10 +328,80 @@ int main(int argc, char **argv)
                "%zu; largest score %.2f, largest sum of exponentials %.3f; max |decrypted - clear attention| %.2e (exact softmax: %.2e)\n",
                head_s, context.get_context_data(out[0].parms_id())->chain_index(), smax, summax, head_err, head_err_true);
     }
+    // ---- 3. a slice of the feed-forward half, MOAI's loops unchanged ----------------------------------------------------
+    double ffn_selfout_s = -1, ffn_inter_s = -1, ffn_final_s = -1, ffn_gelu_s = -1;
+    const int slice_cols = 128, gelu_cts = 128;
+    if (with_ffn)
+    {
+        const int num_col = 768, num_inter = 3072, num_X = 256, num_row = 128, input_num = 5;
+        vector<int> input_len(num_X, 0);
+        input_len[0] = input_num;
+        vector<int> b_vec = bias_vec(input_len, num_X, num_row);
+        // inputs: eight fresh ciphertexts switched down to the stage's chain index, repeated (the work does not depend on the values)
+        auto inputs_at = [&](size_t count, size_t index) {
+            vector<Ciphertext> base(8), out(count);
+            for (int i = 0; i < 8; i++)
+            {
+                vector<double> vals(slot_count, 0.0);
+                for (size_t sidx = 0; sidx < slot_count; sidx++) vals[sidx] = b_vec[sidx] ? 0.5 * ud(rng) : 0.0;
+                Plaintext p;
+                encoder.encode(vals, scale, p);
+                encryptor.encrypt(p, base[i]);
+                while (context.get_context_data(base[i].parms_id())->chain_index() > index) evaluator.mod_switch_to_next_inplace(base[i]);
+            }
+            for (size_t i = 0; i < count; i++) out[i] = base[i % 8];
+            context.sync();
+            return out;
+        };
+        auto weights = [&](int rows, int cols) {
+            vector<vector<double>> W(rows, vector<double>(cols));
+            for (auto &r : W)
+                for (auto &x : r) x = 0.02 * ud(rng);
+            return W;
+        };
+        report_memory("start of the feed-forward slice");
+        {
+            vector<Ciphertext> X = inputs_at(num_col, 1); // test_full_scheme.hpp:601: attention output at chain index 1
+            const auto W = weights(num_col, slice_cols);
+            t0 = now_s();
+            vector<Ciphertext> out = ct_pt_matrix_mul_wo_pre_w_mask(X, W, b_vec, num_col, slice_cols, num_col, context);
+            context.sync();
+            ffn_selfout_s = now_s() - t0;
+        }
+        {
+            vector<Ciphertext> X = inputs_at(num_col, 9); // :768-807: eleven levels below the bootstrap's output
+            const auto W = weights(num_col, slice_cols);
+            t0 = now_s();
+            vector<Ciphertext> out = ct_pt_matrix_mul_wo_pre_large(X, W, num_col, slice_cols, num_col, context);
+            context.sync();
+            ffn_inter_s = now_s() - t0;
+        }
+        {
+            vector<Ciphertext> X = inputs_at(gelu_cts, 8), out(gelu_cts);
+            t0 = now_s();
+#pragma omp parallel for
+            for (int i = 0; i < gelu_cts / 32; i++) // :884-888: 96 x 32 in the reference
+                for (int j = 0; j < 32; j++) out[i * 32 + j] = gelu_v2(X[i * 32 + j], context, relin_keys, secret_key);
+            context.sync();
+            ffn_gelu_s = now_s() - t0;
+        }
+        {
+            vector<Ciphertext> X = inputs_at(num_inter, 1); // :928: GELU's output at chain index 1
+            const auto W = weights(num_inter, slice_cols);
+            t0 = now_s();
+            vector<Ciphertext> out = ct_pt_matrix_mul_wo_pre_w_mask(X, W, b_vec, num_inter, slice_cols, num_inter, context);
+            context.sync();
+            ffn_final_s = now_s() - t0;
+        }
+        printf("feed-forward slice through MOAI's unchanged loops: self-output %d of 768 columns %.2f s, intermediate %d of 3072 columns %.2f s, "
+               "gelu_v2 on %d of 3072 ciphertexts %.2f s, final product %d of 768 columns %.2f s\n",
+               slice_cols, ffn_selfout_s, slice_cols, ffn_inter_s, gelu_cts, ffn_gelu_s, slice_cols, ffn_final_s);
+    }
     printf("E2E_JSON {\"pack\": %d, \"threads\": %d, \"setup_s\": %.2f, \"bootstrap_ms_packed\": %.3f, \"bootstrap_ms_moai_calls\": %.3f, "
            "\"bootstrap_chain_index_after\": %zu, \"bootstrap_max_error\": %.3e, \"head_s\": %.3f, \"head_max_error\": %.3e, "
-           "\"head_max_error_vs_exact_softmax\": %.3e, \"ops_bootstrap_pack\": %s, \"ops_head\": %s}\n",
-           pack, threads, setup_s, boot_packed_ms, boot_calls_ms, boot_index, boot_err, head_s, head_err, head_err_true, ops_boot.c_str(),
-           ops_head.c_str());
+           "\"head_max_error_vs_exact_softmax\": %.3e, \"ffn_slice\": {\"columns\": %d, \"gelu_ciphertexts\": %d, \"selfout_s\": %.3f, "
+           "\"intermediate_s\": %.3f, \"gelu_s\": %.3f, \"final_s\": %.3f}, \"ops_bootstrap_pack\": %s, \"ops_head\": %s}\n",
+           pack, threads, setup_s, boot_packed_ms, boot_calls_ms, boot_index, boot_err, head_s, head_err, head_err_true, slice_cols, gelu_cts,
+           ffn_selfout_s, ffn_inter_s, ffn_gelu_s, ffn_final_s, ops_boot.c_str(), ops_head.c_str());
     return 0;
 }

@@ -393,6 +393,12 @@ int main(int argc, char **argv)
     const bool full = heads >= 12 && boot_packs >= 768 / boot_B && gelu_packs >= 48 && 768 % boot_B == 0;
     fprintf(stderr, "one encoder layer, 256 packed inputs, %s: %.1f s wall (bootstrapping %.1f s = %.0f %%)\n", full ? "complete" : "QUICK RUN (work skipped)", total,
             t_boot, 100 * t_boot / total);
+    // one machine-readable line per layer on stdout (bench.py's end-to-end slice reads it)
+    printf("LAYER_JSON {\"complete\": %s, \"layer_s\": %.3f, \"attention_s\": %.3f, \"selfout_s\": %.3f, \"layernorm1_s\": %.3f, "
+           "\"intermediate_s\": %.3f, \"gelu_s\": %.3f, \"final_s\": %.3f, \"layernorm2_s\": %.3f, \"bootstrap_s\": %.3f, "
+           "\"bootstrap_pack\": %d}\n",
+           full ? "true" : "false", total, t_att, t_so, t_ln1, t_inter, t_gelu, t_final, t_ln2, t_boot, boot_B);
+    fflush(stdout);
     if (full)
     {
         fprintf(stderr, "x 12 layers = %.0f s per batch of 256 inputs = %.2f s per encrypted input (paper: 574.6 s on 56 cores)\n", total * 12, total * 12 / 256);

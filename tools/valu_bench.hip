@@ -104,6 +104,21 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
             B(d0, d1) B(d2, d3) B(d4, d5) B(d6, d7)
 #undef B
         }
+        else if (OP == 14)
+        {
+            // the M_LAZY8 butterfly of the NTT kernels (csrc/modarith.hip.h ct_bfly_lazy8): approximate Shoup quotient from the two
+            // high cross terms, remainder as one multiply-add chain modulo 2^64, sign-tested guard; 4 per iteration
+            const uint64_t q = 1152921504606584833ull, nq = 0 - q, n4q = 0 - 4 * q, tw = 288794978602139552ull, twq = 4620693217682128896ull;
+#define B(x, yv) { uint64_t d = x + n4q; uint64_t u = (int64_t)d < 0 ? x : d; const uint64_t wq_ = twq + w7; \
+                   const uint32_t y0 = (uint32_t)yv, y1 = (uint32_t)(yv >> 32), q0 = (uint32_t)wq_, q1 = (uint32_t)(wq_ >> 32); \
+                   uint64_t t = (uint64_t)y1 * q1 + __umulhi(y1, q0); t += __umulhi(y0, q1); \
+                   const uint32_t t0 = (uint32_t)t, t1 = (uint32_t)(t >> 32), w0_ = (uint32_t)tw, w1_ = (uint32_t)(tw >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32); \
+                   uint64_t p = (uint64_t)y0 * w0_; p += (uint64_t)t0 * n0; \
+                   const uint32_t hi = (uint32_t)(p >> 32) + y0 * w1_ + y1 * w0_ + t0 * n1 + t1 * n0; \
+                   const uint64_t v = ((uint64_t)hi << 32) | (uint32_t)p; x = u + v; yv = u - (v + n4q); }
+            B(w0, w1) B(w2, w3) B(w4, w5) B(w6, w7)
+#undef B
+        }
         else if (OP == 9)
         {
 #define A(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x) : "v"(y));
@@ -205,6 +220,7 @@ int main()
     run<6>("v_lshl_add_u64 (64-bit add)", 8, cus, d);
     run<7>("__umul64hi", 7, cus, d);
     run<8>("shoup butterfly (64-bit)", 4, cus, d);
+    run<14>("lazy8 butterfly (q < 2^60)", 4, cus, d);
     run<10>("v_mul_f64", 8, cus, d);
     run<11>("v_add_f64", 8, cus, d);
     run<12>("v_rndne_f64", 8, cus, d);

@@ -314,6 +314,19 @@ int moai_apply_galois_hoisted(moai_ctx *ctx, const uint64_t *in, uint64_t *const
                               const uint64_t *const *galois_keys, const uint64_t *const *corrections, size_t R, size_t batch,
                               int *used_fallback, void *stream);
 
+/* ---- level-trimmed key residency ------------------------------------------------------------------------------------
+ * switch_key_inplace at l data primes reads only the digits J < l and the rows {0 .. l-1, special prime} of a key
+ * (SEAL/evaluator.cpp:2818, 2831; the reference keeps every key whole, SEAL/kswitchkeys.h:340: 1.32 GB each at MOAI's
+ * parameters).  moai_key_trim copies exactly that part of a key in the reference's layout [k-1][2][k][N] into
+ * `trimmed`, [levels][2][levels+1][N] with the special prime's row last (moai_key_words(ctx, levels) words), and records
+ * the layout of that pointer in the context: every key-switch entry point above accepts it in place of the full key for
+ * l <= levels, with the same results bit for bit (the same words are read), and fails with MOAI_ERANGE for l > levels.
+ * MOAI's 31 default rotation keys are only used at chain index <= 14 (Ct_ct_matrix_mul.hpp:29,95,112,147): 15 levels =
+ * 19 % of the full size.  moai_key_forget drops the record (before the block is freed or reused). */
+size_t moai_key_words(const moai_ctx *ctx, size_t levels);
+int moai_key_trim(moai_ctx *ctx, const uint64_t *full_key, size_t levels, uint64_t *trimmed, void *stream);
+int moai_key_forget(moai_ctx *ctx, const uint64_t *key);
+
 /* ---- stream audit (debug) ----------------------------------------------------------------------------------------
  * A caller that recycles device blocks in a stream-ordered cache (the seal:: shim's util::DevicePool: a released block may be
  * handed out again on the SAME stream without synchronising, which is only safe when everything that touches the block is

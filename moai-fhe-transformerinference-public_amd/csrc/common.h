@@ -135,6 +135,13 @@ struct moai_ctx
     std::vector<double> ckks_inv_roots_host;  // inv_root_powers_ [N] (re, im)
     uint32_t *ckks_src_map = nullptr;         // device, inverse of ckks_index_map
     double *ckks_inv_roots = nullptr;         // device copy
+    // Key layouts (moai_key_trim): a key-switch key registered here is [digits][2][rows][N] with the special prime's row last
+    // instead of the reference's [k-1][2][k][N]; unregistered pointers have the reference's layout.
+    struct KeyLayout
+    {
+        uint32_t digits, rows;
+    };
+    std::map<const void *, KeyLayout> key_layouts;
     void *mutex = nullptr;
     // serialises the enqueue of multi-kernel operations that share a stream's workspace arena: callers
     // on different host threads may target the same stream (MOAI's OpenMP loops do)

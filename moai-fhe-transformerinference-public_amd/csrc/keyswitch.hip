@@ -174,7 +174,8 @@ struct MacArgs
     uint64_t *acc;         // [B][2][L+1][N]
     const PrimeConst *pc;
     uint32_t L;
-    uint32_t k;
+    uint32_t k;            // rows per key polynomial in the key's layout
+    uint32_t krow;         // the key row of prime I in that layout (the special prime's is the last)
     uint32_t prime;        // I (context prime index)
     uint32_t slot;         // row of acc to write (I, or L for the special prime)
     uint32_t n2;
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(256) void keyswitch_mac_kernel(MacArgs g)
         for (uint32_t J = 0; J < g.L; ++J)
         {
             ulonglong2 o = ops[(size_t)J * n2 + j];
-            ulonglong2 k0 = key[((size_t)(J * 2 + 0) * g.k + g.prime) * n2 + j];
-            ulonglong2 k1 = key[((size_t)(J * 2 + 1) * g.k + g.prime) * n2 + j];
+            ulonglong2 k0 = key[((size_t)(J * 2 + 0) * g.k + g.krow) * n2 + j];
+            ulonglong2 k1 = key[((size_t)(J * 2 + 1) * g.k + g.krow) * n2 + j];
             mac128(l0x, h0x, o.x, k0.x);
             mac128(l0y, h0y, o.y, k0.y);
             mac128(l1x, h1x, o.x, k1.x);
@@ -443,7 +444,28 @@ struct KsTarget
 {
     const uint64_t *ptr; // NTT-form target rows
     uint32_t stride_rows, off_rows;
+    uint32_t key_rows;   // rows per key polynomial in the key's layout (key_rows_for)
 };
+
+// rows per key polynomial of `key` (k for the reference's layout, levels + 1 for a key moai_key_trim produced), after checking
+// that the key holds what a switch at L data primes reads: digits J < L and rows {0 .. L-1, special} (SEAL/evaluator.cpp:2818,2831)
+static int key_rows_for(moai_ctx *c, const uint64_t *key, size_t L, uint32_t *rows)
+{
+    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+    auto it = c->key_layouts.find(key);
+    if (it == c->key_layouts.end())
+    {
+        *rows = (uint32_t)c->k;
+        return MOAI_OK;
+    }
+    if (L > it->second.digits || L + 1 > it->second.rows)
+    {
+        return set_error(MOAI_ERANGE, "the key was trimmed to %u levels and cannot switch a ciphertext of %zu data primes",
+                         it->second.digits, L);
+    }
+    *rows = it->second.rows;
+    return MOAI_OK;
+}
 
 template <int LOGN>
 static int ks_fused_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *key, uint64_t *acc, size_t L,
@@ -563,7 +585,7 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.grp = grp;
     p2.L = (uint32_t)L;
     p2.G = (uint32_t)G;
-    p2.k = (uint32_t)c->k;
+    p2.k = tg.key_rows;
     p2.B = (uint32_t)batch;
     p2.S = splits;
     p2.jchunk = (uint32_t)((L + splits - 1) / splits);
@@ -603,6 +625,14 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     if (L > k - 1)
     {
         return set_error(MOAI_EINVAL, "L exceeds the key's decomposition size");
+    }
+    uint32_t key_rows = 0;
+    {
+        const int krc = key_rows_for(c, key, L, &key_rows);
+        if (krc)
+        {
+            return krc;
+        }
     }
     const size_t row_bytes = n * sizeof(uint64_t);
     const size_t sz_t = align256(batch * L * row_bytes);
@@ -650,6 +680,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         tg.ptr = target;
         tg.stride_rows = (uint32_t)target_stride_rows;
         tg.off_rows = (uint32_t)target_off_rows;
+        tg.key_rows = key_rows;
         std::vector<uint16_t> order;
         std::vector<int> order_mode;
         for (int mode = M_FPR; mode >= M_GUARD; --mode)
@@ -728,7 +759,8 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             m.acc = acc;
             m.pc = c->pc;
             m.L = (uint32_t)L;
-            m.k = (uint32_t)k;
+            m.k = key_rows;
+            m.krow = Iidx == L ? key_rows - 1 : prime;
             m.prime = prime;
             m.slot = (uint32_t)Iidx;
             m.n2 = n2;
@@ -1134,7 +1166,7 @@ static void hoist_contig_finish(moai_ctx *c, uint64_t *tmp, size_t L, size_t bat
 template <int LOGN>
 static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint64_t *in, size_t L, size_t batch, const KsGroup &grp,
                        size_t G, int mode, const uint32_t *const *tables, const uint32_t *const *itables, const uint64_t *const *keys,
-                       const uint64_t *const *corrs, uint64_t *acc, size_t acc_stride_words, size_t R, hipStream_t s)
+                       const uint32_t *key_rows, const uint64_t *const *corrs, uint64_t *acc, size_t acc_stride_words, size_t R, hipStream_t s)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     KsP1Args p1;
@@ -1172,6 +1204,7 @@ static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint
                 const size_t rr = r + (h < nr ? h : 0);
                 m2.itable[h] = itables[rr];
                 m2.key[h] = keys[rr];
+                m2.krows[h] = key_rows[rr];
                 m2.corr[h] = corrs[rr];
                 m2.acc[h] = acc + rr * acc_stride_words;
             }
@@ -1212,7 +1245,7 @@ static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint
         m.grp = grp;
         m.L = (uint32_t)L;
         m.G = (uint32_t)G;
-        m.k = (uint32_t)c->k;
+        m.k = key_rows[r];
         m.B = (uint32_t)batch;
         m.total_work = (uint32_t)(batch * G * TPR * 2);
         if (mode == M_FPN)
@@ -1256,6 +1289,12 @@ extern "C" int moai_hoist_correction(moai_ctx *c, const uint64_t *galois_key, ui
     {
         return set_error(MOAI_EINVAL, "Galois element is not valid");
     }
+    uint32_t key_rows = 0;
+    rc = key_rows_for(c, galois_key, L, &key_rows);
+    if (rc)
+    {
+        return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     const size_t row_bytes = c->n * sizeof(uint64_t);
     std::lock_guard<std::mutex> op_lock(*static_cast<std::mutex *>(c->op_mutex));
@@ -1293,6 +1332,7 @@ extern "C" int moai_hoist_correction(moai_ctx *c, const uint64_t *galois_key, ui
     g.pc = c->pc;
     g.L = (uint32_t)L;
     g.k = (uint32_t)c->k;
+    g.krows = key_rows;
     g.n2 = (uint32_t)(c->n >> 1);
     MOAI_CHECK_GRID_ROWS(2 * (L + 1));
     hipLaunchKernelGGL(ks_hoist_correction_kernel, rgrid(c, 2 * (L + 1)), dim3(256), 0, s, g);
@@ -1379,6 +1419,15 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
             inv = (inv * (2u - galois_elts[r] * inv)) & two_n_mask;
         }
         rc = galois_table(c, inv, s, &itables[r]);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    std::vector<uint32_t> key_rows(R);
+    for (size_t r = 0; r < R; ++r)
+    {
+        rc = key_rows_for(c, galois_keys[r], L, &key_rows[r]);
         if (rc)
         {
             return rc;
@@ -1471,11 +1520,11 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
                 }
                 switch (c->logn)
                 {
-                case 12: rc = hoist_group<12>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                case 13: rc = hoist_group<13>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                case 14: rc = hoist_group<14>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                case 15: rc = hoist_group<15>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
-                default: rc = hoist_group<16>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, corrections, acc, acc_stride_words, R, s); break;
+                case 12: rc = hoist_group<12>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, key_rows.data(), corrections, acc, acc_stride_words, R, s); break;
+                case 13: rc = hoist_group<13>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, key_rows.data(), corrections, acc, acc_stride_words, R, s); break;
+                case 14: rc = hoist_group<14>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, key_rows.data(), corrections, acc, acc_stride_words, R, s); break;
+                case 15: rc = hoist_group<15>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, key_rows.data(), corrections, acc, acc_stride_words, R, s); break;
+                default: rc = hoist_group<16>(c, t, tmp, in, L, batch, grp, g, mode, tables.data(), itables.data(), galois_keys, key_rows.data(), corrections, acc, acc_stride_words, R, s); break;
                 }
                 if (rc)
                 {
@@ -1519,5 +1568,68 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
             return rc;
         }
     }
+    return MOAI_OK;
+}
+
+// ---- level-trimmed key residency ------------------------------------------------------------------------------------------------
+extern "C" size_t moai_key_words(const moai_ctx *c, size_t levels)
+{
+    if (!c || c->k < 2)
+    {
+        return 0;
+    }
+    const size_t lv = levels > c->k - 1 ? c->k - 1 : levels;
+    return lv * 2 * (lv + 1) * c->n;
+}
+
+extern "C" int moai_key_trim(moai_ctx *c, const uint64_t *full_key, size_t levels, uint64_t *trimmed, void *stream)
+{
+    MOAI_AUDIT(stream, full_key, trimmed);
+    if (!c || !full_key || !trimmed)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    int rc = enter_device(c);
+    if (rc)
+    {
+        return rc;
+    }
+    const size_t k = c->k, n = c->n;
+    if (k < 2 || levels < 1 || levels > k - 1)
+    {
+        return set_error(MOAI_EINVAL, "levels must lie in 1 .. %zu", k < 2 ? (size_t)0 : k - 1);
+    }
+    {
+        std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+        if (c->key_layouts.count(full_key))
+        {
+            return set_error(MOAI_EINVAL, "the source of moai_key_trim must be a key in the reference's layout");
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = levels + 1;
+    for (size_t J = 0; J < levels; ++J)
+    {
+        for (size_t K = 0; K < 2; ++K)
+        {
+            const uint64_t *src = full_key + (J * 2 + K) * k * n;
+            uint64_t *dst = trimmed + (J * 2 + K) * rows * n;
+            MOAI_HIP_CHECK(hipMemcpyAsync(dst, src, levels * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+            MOAI_HIP_CHECK(hipMemcpyAsync(dst + levels * n, src + (k - 1) * n, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+    c->key_layouts[trimmed] = moai_ctx::KeyLayout{ (uint32_t)levels, (uint32_t)rows };
+    return MOAI_OK;
+}
+
+extern "C" int moai_key_forget(moai_ctx *c, const uint64_t *key)
+{
+    if (!c)
+    {
+        return set_error(MOAI_EINVAL, "null context");
+    }
+    std::lock_guard<std::mutex> g(*static_cast<std::mutex *>(c->mutex));
+    c->key_layouts.erase(key);
     return MOAI_OK;
 }

@@ -101,7 +101,8 @@ struct KsP2Args
     const uint64_t *tmp; // [B][G][L][N]
     const uint64_t *tgt; // the target in NTT form: row (b, J) at tgt + ((b * tgt_stride + tgt_off + J) << LOGN)
     uint32_t tgt_stride, tgt_off;
-    const uint64_t *key; // [k-1][2][k][N]
+    const uint64_t *key; // [digits][2][k][N]: k rows per key polynomial, the special prime's row LAST (the reference's
+                         // layout has k = all primes, SEAL/kswitchkeys.h:340; a level-trimmed key fewer, moai_key_trim)
     uint64_t *acc;       // [B][2][L+1][N]
     const Tw *tw;
     const double *tw1;   // FP64 modes: the forward powers as plain doubles
@@ -330,10 +331,11 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             }
         }
         } // !direct
+        const uint32_t krow = slot == a.L ? a.k - 1 : prime; // the special prime's row is the last one of the key's layout
         const ulonglong2 *__restrict__ k0 =
-            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + krow) << LOGN)) + ((size_t)tile << 10) + ch0;
         const ulonglong2 *__restrict__ k1 =
-            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN)) + ((size_t)tile << 10) + ch0;
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + krow) << LOGN)) + ((size_t)tile << 10) + ch0;
         if (MODE >= M_FPN)
         {
             // FP64 modes: the MAC stays on the FP64 pipe as well.  The digit is reduced to |v| <= q/2 so that
@@ -441,6 +443,7 @@ struct HoistCorrArgs
     uint64_t *out;         // [2][L+1][N]
     const PrimeConst *pc;
     uint32_t L, k, n2;
+    uint32_t krows;        // rows per key polynomial in the key's layout (k for the reference's, fewer for a trimmed key)
 };
 
 // out[K][slot] = mask[slot] (*) sum_{J < L} (q_J mod q_slot) key[J][K][slot]      blockIdx.y = K * (L + 1) + slot
@@ -462,7 +465,8 @@ __global__ __launch_bounds__(256) void ks_hoist_correction_kernel(HoistCorrArgs 
                 continue; // q_J mod q_J = 0: the digit under its own prime is the target row itself
             }
             const uint64_t delta = barrett64(g.pc[J].q, q, cr1);
-            const ulonglong2 kv = (reinterpret_cast<const ulonglong2 *>(g.key) + ((size_t)(J * 2 + K) * g.k + prime) * g.n2)[j];
+            const ulonglong2 kv =
+                (reinterpret_cast<const ulonglong2 *>(g.key) + ((size_t)(J * 2 + K) * g.krows + (slot == g.L ? g.krows - 1 : slot)) * g.n2)[j];
             mac128r(lx, hx, kv.x, delta);
             mac128r(ly, hy, kv.y, delta);
         }
@@ -552,8 +556,9 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac(HoistMacArgs a)
     {
         const uint64_t *__restrict__ row = (slot == J) ? a.ct + (((size_t)(bq * 2 + 1) * a.L + J) << LOGN)
                                                        : a.dig + ((((size_t)bq * a.G + g) * a.L + J) << LOGN);
-        const uint64_t *__restrict__ k0 = a.key + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN) + obase;
-        const uint64_t *__restrict__ k1 = a.key + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN) + obase;
+        const uint32_t krow = slot == a.L ? a.k - 1 : prime; // a.k = rows per key polynomial in this key's layout
+        const uint64_t *__restrict__ k0 = a.key + (((size_t)(J * 2 + 0) * a.k + krow) << LOGN) + obase;
+        const uint64_t *__restrict__ k1 = a.key + (((size_t)(J * 2 + 1) * a.k + krow) << LOGN) + obase;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
         {
@@ -618,6 +623,7 @@ struct HoistMac2Args
     const PrimeConst *pc;
     KsGroup grp;
     uint32_t L, G, k, B;
+    uint32_t krows[4];     // rows per key polynomial of each rotation's key
     uint32_t total_work;
 };
 
@@ -665,8 +671,9 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac2(HoistMac2Args a)
 #pragma unroll
             for (int r = 0; r < NR; ++r)
             {
-                const uint64_t *__restrict__ k0 = a.key[r] + (((size_t)(J * 2 + 0) * a.k + prime) << LOGN);
-                const uint64_t *__restrict__ k1 = a.key[r] + (((size_t)(J * 2 + 1) * a.k + prime) << LOGN);
+                const uint32_t kr = a.krows[r], krow = slot == a.L ? kr - 1 : prime;
+                const uint64_t *__restrict__ k0 = a.key[r] + (((size_t)(J * 2 + 0) * kr + krow) << LOGN);
+                const uint64_t *__restrict__ k1 = a.key[r] + (((size_t)(J * 2 + 1) * kr + krow) << LOGN);
 #pragma unroll
                 for (int e = 0; e < E; ++e)
                 {

@@ -76,6 +76,9 @@ SYMBOLS = {
     "moai_mem_info": (C.c_int, [C.POINTER(sz), C.POINTER(sz)]),
     "moai_op_trace": (C.c_int, [C.c_int]),
     "moai_op_trace_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "moai_key_words": (sz, [vp, sz]),
+    "moai_key_trim": (C.c_int, [vp, vp, sz, vp, vp]),
+    "moai_key_forget": (C.c_int, [vp, vp]),
     "moai_debug_stream_audit": (C.c_int, [C.c_int]),
     "moai_debug_block_label": (None, [vp, sz, vp, C.c_int]),
     "moai_debug_stream_audit_counts": (None, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
@@ -315,6 +318,17 @@ class Context:
 
     def apply_galois_to(self, src, dst, L, elt, key, batch, stream=None):
         _check(lib().moai_apply_galois_to(self.h, _ptr(src), _ptr(dst), L, int(elt), _ptr(key), batch, stream))
+
+    def key_trim(self, full_key, levels, stream=None):
+        """the part of a key a switch at <= `levels` data primes reads, as a DeviceBuffer [levels][2][levels+1][N] whose layout the
+        context knows (moai_key_trim); pass it wherever a key is expected"""
+        out = DeviceBuffer(lib().moai_key_words(self.h, levels))
+        _check(lib().moai_key_trim(self.h, _ptr(full_key), levels, out.ptr, stream))
+        _check(lib().moai_stream_sync(stream))
+        return out
+
+    def key_forget(self, key):
+        _check(lib().moai_key_forget(self.h, _ptr(key)))
 
     def hoist_correction(self, key, elt, L, stream=None):
         """the per-(key, level) constant of the hoisted rotations: DeviceBuffer [2][L+1][N]"""

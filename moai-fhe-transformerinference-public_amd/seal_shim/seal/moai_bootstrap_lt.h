@@ -306,10 +306,10 @@ namespace moai_fused
                     {
                         for (std::size_t h = 0; h + 1 < seq.size(); h++)
                         {
-                            util::hip_check(moai_apply_galois(dev, dst, L, seq[h], gal_keys.device_key(seal::GaloisKeys::get_index(seq[h])), B, st));
+                            util::hip_check(moai_apply_galois(dev, dst, L, seq[h], gal_keys.device_key(seal::GaloisKeys::get_index(seq[h]), L), B, st));
                         }
                         util::hip_check(moai_apply_galois_acc(dev, dst, acc.get(), L, seq.back(),
-                                                              gal_keys.device_key(seal::GaloisKeys::get_index(seq.back())), B, st));
+                                                              gal_keys.device_key(seal::GaloisKeys::get_index(seq.back()), L), B, st));
                         return;
                     }
                 }
@@ -436,7 +436,7 @@ namespace moai_fused
                 elts[i] = seq[0];
                 rest[i].assign(seq.begin() + 1, seq.end());
                 const std::size_t index = seal::GaloisKeys::get_index(seq[0]);
-                kptr[i] = keys.device_key(index);
+                kptr[i] = keys.device_key(index, L);
                 cptr[i] = keys.hoist_correction(context_, index, seq[0], L);
                 optr[i] = babies + k * batch_words;
                 i++;
@@ -448,7 +448,7 @@ namespace moai_fused
             {
                 for (std::uint32_t elt : rest[i])
                 {
-                    seal::util::hip_check(moai_apply_galois(context_.device(), optr[i], L, elt, keys.device_key(seal::GaloisKeys::get_index(elt)), B,
+                    seal::util::hip_check(moai_apply_galois(context_.device(), optr[i], L, elt, keys.device_key(seal::GaloisKeys::get_index(elt), L), B,
                                                             context_.stream()));
                 }
             }
@@ -470,7 +470,7 @@ namespace moai_fused
             {
                 const std::uint32_t elt = seq[h];
                 seal::util::hip_check(moai_apply_galois_to(context_.device(), h == 0 ? src : dst, dst, L, elt,
-                                                           keys.device_key(seal::GaloisKeys::get_index(elt)), B, context_.stream()));
+                                                           keys.device_key(seal::GaloisKeys::get_index(elt), L), B, context_.stream()));
             }
         }
 
@@ -483,7 +483,7 @@ namespace moai_fused
             for (std::uint32_t elt : seq)
             {
                 seal::util::hip_check(moai_apply_galois(context_.device(), data, L, elt,
-                                                        keys.device_key(seal::GaloisKeys::get_index(elt)), B, context_.stream()));
+                                                        keys.device_key(seal::GaloisKeys::get_index(elt), L), B, context_.stream()));
             }
         }
 

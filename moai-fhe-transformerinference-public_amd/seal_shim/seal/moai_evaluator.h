@@ -230,7 +230,7 @@ namespace seal
                 const std::size_t stride = size * rn;
                 while (size > 2)
                 {
-                    const std::uint64_t *key = relin_keys.device_key(RelinKeys::get_index(size - 1));
+                    const std::uint64_t *key = relin_keys.device_key(RelinKeys::get_index(size - 1), L);
                     for (std::size_t b = 0; b < B; b++)
                     {
                         std::uint64_t *ct = encrypted.device_data() + b * stride;
@@ -254,7 +254,7 @@ namespace seal
             util::OpCombiner &comb = util::OpCombiner::instance();
             if (encrypted.batch() == 1 && comb.enabled())
             {
-                const std::uint64_t *key = relin_keys.device_key(0);
+                const std::uint64_t *key = relin_keys.device_key(0, L);
                 const std::size_t rn = L * encrypted.poly_modulus_degree();
                 comb.submit(util::OpCombiner::Key(1, L, 0, key, dev()), { encrypted.device_data(), out.device_data() },
                             [&](const std::vector<util::OpCombiner::Request> &reqs) {
@@ -277,7 +277,7 @@ namespace seal
             }
             else
             {
-                hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0), out.device_data(), L,
+                hip(moai_relinearize(dev(), encrypted.device_data(), relin_keys.device_key(0, L), out.device_data(), L,
                                      encrypted.batch(), st()));
             }
             out.is_ntt_form() = true;
@@ -1009,8 +1009,8 @@ namespace seal
             {
                 like(dst, src);
             }
-            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt));
             const std::size_t L = src.coeff_modulus_size();
+            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt), L);
             util::OpCombiner &comb = util::OpCombiner::instance();
             if (src.batch() == 1 && comb.enabled())
             {

@@ -456,7 +456,7 @@ namespace moai_fused
                 kids.emplace_back(cols * ct_words, st);
                 elts.push_back(kv.first);
                 const std::size_t index = GaloisKeys::get_index(kv.first);
-                kptr.push_back(RotK.device_key(index));
+                kptr.push_back(RotK.device_key(index, L));
                 optr.push_back(kids.back().get());
             }
             if (hoist && elts.size() >= 2 && seal_context.logn() >= 12)
@@ -486,7 +486,7 @@ namespace moai_fused
         };
         walk(root, dW.get());
         util::DeviceArray d2(rows * ct_words, st), dres(rows * 2 * (L - 1) * n, st);
-        util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0), d2.get(), L, rows, st));
+        util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0, L), d2.get(), L, rows, st));
         util::hip_check(moai_rescale(dev, d2.get(), dres.get(), 2, L, rows, st));
         const parms_id_type next_id = cd->next_context_data()->parms_id();
         for (std::size_t i = 0; i < rows; i++)
@@ -580,7 +580,7 @@ namespace moai_fused
             detail::rotation_sequence(seal_context, RotK, step, seq);
             for (std::uint32_t elt : seq)
             {
-                util::hip_check(moai_apply_galois(dev, data, L, elt, RotK.device_key(GaloisKeys::get_index(elt)), count, st));
+                util::hip_check(moai_apply_galois(dev, data, L, elt, RotK.device_key(GaloisKeys::get_index(elt), L), count, st));
             }
         };
         // rot_enc_X[index], index = i*g + j: enc_X[index] rotated by (col_X - i*g) * num_batch (:86-101)
@@ -637,7 +637,7 @@ namespace moai_fused
             }
         }
         util::DeviceArray d2(cols * Bg * ctw, st), dres(cols * Bg * 2 * (L - 1) * n, st);
-        util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0), d2.get(), L, cols * Bg, st));
+        util::hip_check(moai_relinearize(dev, d3.get(), relin_keys.device_key(0, L), d2.get(), L, cols * Bg, st));
         util::hip_check(moai_rescale(dev, d2.get(), dres.get(), 2, L, cols * Bg, st));
         // output[i] = out[i][0] + sum_{j>=1} rotate(out[i][j], j*g*num_batch) (:142-150); layout [j][i]
         const std::size_t Lr = L - 1, rw = 2 * Lr * n;
@@ -648,7 +648,7 @@ namespace moai_fused
             detail::rotation_sequence(seal_context, RotK, static_cast<int>(j * G) * num_batch, seq);
             for (std::uint32_t elt : seq)
             {
-                util::hip_check(moai_apply_galois(dev, blk, Lr, elt, RotK.device_key(GaloisKeys::get_index(elt)), cols, st));
+                util::hip_check(moai_apply_galois(dev, blk, Lr, elt, RotK.device_key(GaloisKeys::get_index(elt), Lr), cols, st));
             }
             util::hip_check(moai_add(dev, dres.get(), blk, dres.get(), cols * 2, Lr, st));
         }

@@ -1325,7 +1325,68 @@ namespace seal
         }
         const std::uint64_t *device_key(std::size_t index) const
         {
-            return index < keys_.size() && keys_[index] ? keys_[index]->get() : nullptr;
+            if (index >= keys_.size() || !keys_[index])
+            {
+                return nullptr;
+            }
+            if (res_)
+            {
+                std::lock_guard<std::mutex> g(res_->mu);
+                if (index < res_->regrown.size() && res_->regrown[index])
+                {
+                    return res_->regrown[index]->get();
+                }
+            }
+            return keys_[index]->get();
+        }
+        // the key for a switch at L data primes: the same pointer unless the key was trimmed below L (limit_to_chain_index),
+        // in which case the full key comes back from its host copy first
+        const std::uint64_t *device_key(std::size_t index, std::size_t L) const;
+
+        // ---- level-trimmed residency (not part of the reference API) ---------------------------------------------------
+        // A key switch at l data primes reads the digits J < l and the rows {0 .. l-1, special prime} of a key
+        // (SEAL/evaluator.cpp:2818, 2831); the reference keeps all of every key resident (1.32 GB each at MOAI's parameters).
+        // limit_to_chain_index keeps on the device only what ciphertexts at chain index <= `chain_index` need (moai_key_trim:
+        // (c+1) (c+2) / (35 * 36) of the key) and, unless told otherwise, parks the full key in host memory; a later switch at
+        // a higher level brings the full key back (device_key(index, L)), so results never depend on the call.  MOAI's 31
+        // default rotation keys serve Q K^T and softmax . V at chain index <= 14 only (Ct_ct_matrix_mul.hpp:29,95,112,147).
+        void limit_to_chain_index(const SEALContext &context, std::size_t chain_index, bool keep_host_copy = true);
+        std::size_t device_bytes() const
+        {
+            std::size_t b = 0;
+            for (std::size_t i = 0; i < keys_.size(); i++)
+            {
+                if (!keys_[i])
+                {
+                    continue;
+                }
+                std::shared_ptr<util::DeviceArray> cur = keys_[i];
+                if (res_)
+                {
+                    std::lock_guard<std::mutex> g(res_->mu);
+                    if (i < res_->regrown.size() && res_->regrown[i])
+                    {
+                        cur = res_->regrown[i];
+                    }
+                }
+                b += cur->size() * sizeof(std::uint64_t);
+            }
+            return b;
+        }
+        // how many trimmed keys had to come back whole so far
+        std::size_t regrown_count() const
+        {
+            if (!res_)
+            {
+                return 0;
+            }
+            std::lock_guard<std::mutex> g(res_->mu);
+            std::size_t c = 0;
+            for (auto &r : res_->regrown)
+            {
+                c += r ? 1 : 0;
+            }
+            return c;
         }
         // the per-(key, level) constant of hoisted rotations (moai_hoist_correction), computed on first use and kept for
         // the lifetime of the key object; [2][L+1][N] on the device
@@ -1334,13 +1395,22 @@ namespace seal
     protected:
         friend class KeyGenerator;
         parms_id_type parms_id_ = parms_id_zero;
-        std::vector<std::shared_ptr<util::DeviceArray>> keys_;
+        mutable std::vector<std::shared_ptr<util::DeviceArray>> keys_;
         struct HoistCache
         {
             std::mutex mu;
             std::map<std::pair<std::size_t, std::size_t>, std::shared_ptr<util::DeviceArray>> blocks;
         };
         mutable std::shared_ptr<HoistCache> hoist_ = std::make_shared<HoistCache>();
+        struct Residency
+        {
+            std::mutex mu;
+            std::unique_ptr<SEALContext> context;                        // keeps the device context alive for the records below
+            std::vector<std::size_t> levels;                             // data primes a trimmed key serves (0 = not trimmed)
+            std::vector<std::shared_ptr<std::vector<std::uint64_t>>> host; // the full key, parked
+            std::vector<std::shared_ptr<util::DeviceArray>> regrown;     // the full key, back on the device
+        };
+        std::shared_ptr<Residency> res_;
     };
 
     class RelinKeys : public KSwitchKeys
@@ -1376,10 +1446,96 @@ namespace seal
             return device_key(get_index(galois_elt)) != nullptr;
         }
     };
+    inline void KSwitchKeys::limit_to_chain_index(const SEALContext &context, std::size_t chain_index, bool keep_host_copy)
+    {
+        const std::size_t k = context.key_context_data()->parms().coeff_modulus().size(), n = context.n();
+        const std::size_t levels = chain_index + 1;
+        if (k < 2 || levels >= k - 1)
+        {
+            return; // nothing to drop
+        }
+        if (!res_)
+        {
+            res_ = std::make_shared<Residency>();
+            res_->context.reset(new SEALContext(context));
+        }
+        context.sync();
+        std::lock_guard<std::mutex> g(res_->mu);
+        res_->levels.resize(keys_.size(), 0);
+        res_->host.resize(keys_.size());
+        res_->regrown.resize(keys_.size());
+        const std::size_t full_words = (k - 1) * 2 * k * n;
+        for (std::size_t i = 0; i < keys_.size(); i++)
+        {
+            if (!keys_[i] || res_->regrown[i] || (res_->levels[i] && res_->levels[i] <= levels))
+            {
+                continue; // absent, already whole again (it was needed), or already trimmed at least this far
+            }
+            if (res_->levels[i])
+            {
+                continue; // trimmed to more levels than asked: cutting further needs the full key; leave it
+            }
+            if (keys_[i]->size() != full_words)
+            {
+                throw std::logic_error("limit_to_chain_index: key is not in the reference's layout");
+            }
+            if (keep_host_copy)
+            {
+                auto h = std::make_shared<std::vector<std::uint64_t>>(full_words);
+                util::hip_check(moai_memcpy_d2h(h->data(), keys_[i]->get(), full_words * 8, context.stream()));
+                context.sync();
+                res_->host[i] = h;
+            }
+            // the library keeps the layout of the trimmed block by its address: forget it before the block goes back to the pool
+            std::shared_ptr<SEALContext> keep(new SEALContext(context));
+            std::shared_ptr<util::DeviceArray> t(new util::DeviceArray(moai_key_words(context.device(), levels), context.stream()),
+                                                 [keep](util::DeviceArray *p) {
+                                                     moai_key_forget(keep->device(), p->get());
+                                                     delete p;
+                                                 });
+            util::hip_check(moai_key_trim(context.device(), keys_[i]->get(), levels, t->get(), context.stream()));
+            context.sync(); // the full block is released behind the copy
+            keys_[i] = t;
+            res_->levels[i] = levels;
+        }
+    }
+    inline const std::uint64_t *KSwitchKeys::device_key(std::size_t index, std::size_t L) const
+    {
+        if (index >= keys_.size() || !keys_[index])
+        {
+            return nullptr;
+        }
+        if (!res_)
+        {
+            return keys_[index]->get();
+        }
+        std::lock_guard<std::mutex> g(res_->mu);
+        if (index < res_->regrown.size() && res_->regrown[index])
+        {
+            return res_->regrown[index]->get();
+        }
+        if (index >= res_->levels.size() || res_->levels[index] == 0 || L <= res_->levels[index])
+        {
+            return keys_[index]->get();
+        }
+        // a switch above the level the key was trimmed to: the full key comes back.  The trimmed block stays where it is
+        // (callers on other threads may hold its address); it is dropped with the key object.
+        if (!res_->host[index])
+        {
+            throw std::logic_error("key was trimmed to " + std::to_string(res_->levels[index]) + " levels without a host copy and is asked for " +
+                                   std::to_string(L));
+        }
+        const SEALContext &context = *res_->context;
+        auto full = std::make_shared<util::DeviceArray>(res_->host[index]->size(), context.stream());
+        util::hip_check(moai_memcpy_h2d(full->get(), res_->host[index]->data(), res_->host[index]->size() * 8, context.stream()));
+        context.sync();
+        res_->regrown[index] = full;
+        return full->get();
+    }
     inline const std::uint64_t *KSwitchKeys::hoist_correction(const SEALContext &context, std::size_t index, std::uint32_t galois_elt,
                                                               std::size_t L) const
     {
-        const std::uint64_t *key = device_key(index);
+        const std::uint64_t *key = device_key(index, L);
         if (!key)
         {
             throw std::invalid_argument("Galois key not present");

@@ -183,6 +183,14 @@ int main(int argc, char **argv)
     keygen.create_relin_keys(relin_keys);
     GaloisKeys gal_keys;
     keygen.create_galois_keys(gal_keys);
+    // The default rotation keys serve Q K^T and softmax . V only, at chain index <= 14 (Ct_ct_matrix_mul.hpp:29,95,112,147 called from
+    // single_att_block.hpp:119,197): keep on the device what those levels read -- 19 percent of 41 GB -- and park the rest in host
+    // memory (KSwitchKeys::limit_to_chain_index; a switch at a higher level would bring a key back whole, same bits either way).
+    // MOAI_KEEP_FULL_KEYS=1 leaves them whole.
+    if (!getenv("MOAI_KEEP_FULL_KEYS"))
+    {
+        gal_keys.limit_to_chain_index(context, 14);
+    }
     GaloisKeys gal_keys_boot;
     Encryptor encryptor(context, public_key);
     Decryptor decryptor(context, secret_key);

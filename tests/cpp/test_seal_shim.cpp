@@ -711,6 +711,97 @@ static void regenerated_keys_and_hoisting()
     CHECK(hoisted_equals_separate(later_copy));
 }
 
+// Level-trimmed key residency (KSwitchKeys::limit_to_chain_index): rotations and relinearizations at or below the limit give
+// the bits they gave with the full keys (they read the same words); one above the limit brings the full key back from its host
+// copy -- same bits again -- and the device footprint is what the formula says.
+static void trimmed_keys()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    const size_t N = 4096;
+    parms.set_poly_modulus_degree(N);
+    parms.set_coeff_modulus(CoeffModulus::Create(N, { 51, 46, 46, 46, 51, 58 }));
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    Encryptor encryptor(context, pk);
+    CKKSEncoder encoder(context);
+    Evaluator evaluator(context, encoder);
+    RelinKeys rk;
+    keygen.create_relin_keys(rk);
+    GaloisKeys gk;
+    keygen.create_galois_keys(vector<int>{ 1, 2, 3, 8, -1 }, gk); // 7 = 8 - 1 in non-adjacent form
+    vector<double> v(encoder.slot_count());
+    for (size_t i = 0; i < v.size(); i++) v[i] = 0.001 * (double)(i % 89);
+    Plaintext p;
+    encoder.encode(v, pow(2.0, 40), p);
+    Ciphertext top;
+    encryptor.encrypt(p, top); // chain index 4: five data primes
+    auto at_index = [&](size_t index) {
+        Ciphertext c = top;
+        while (context.get_context_data(c.parms_id())->chain_index() > index) evaluator.mod_switch_to_next_inplace(c);
+        return c;
+    };
+    auto program = [&](size_t index) {
+        // rotate by a step with its own key, by one without (NAF: 1 + 2 + ... ), square + relinearize
+        Ciphertext c = at_index(index), r1, r2, sq;
+        evaluator.rotate_vector(c, 3, gk, r1);
+        evaluator.rotate_vector(c, 7, gk, r2);
+        evaluator.square(c, sq);
+        evaluator.relinearize_inplace(sq, rk);
+        vector<vector<uint64_t>> out = { r1.download(), r2.download(), sq.download() };
+        return out;
+    };
+    const auto full_low = program(1), full_high = program(3);
+    const size_t bytes_full = gk.device_bytes();
+    gk.limit_to_chain_index(context, 1);
+    rk.limit_to_chain_index(context, 1);
+    // 2 levels of 5 digits, 3 of 6 rows: 2 * 3 / (5 * 6) of the full size per key
+    CHECK(gk.device_bytes() * 5 == bytes_full);
+    CHECK(program(1) == full_low && program(0).size() == 3);
+    CHECK(gk.regrown_count() == 0 && rk.regrown_count() == 0);
+    // the hoisted path takes the trimmed key and a correction computed from it
+    {
+        Ciphertext c = at_index(1);
+        const size_t L = c.coeff_modulus_size();
+        vector<Ciphertext> hoisted(2);
+        vector<uint32_t> elts;
+        vector<const uint64_t *> kptr, cptr;
+        vector<uint64_t *> optr;
+        const int steps[2] = { 1, 2 };
+        for (int r = 0; r < 2; r++)
+        {
+            hoisted[r].resize(context, c.parms_id(), 2);
+            const uint32_t e = moai_galois_elt_from_step(context.device(), steps[r]);
+            elts.push_back(e);
+            kptr.push_back(gk.device_key(GaloisKeys::get_index(e), L));
+            cptr.push_back(gk.hoist_correction(context, GaloisKeys::get_index(e), e, L));
+            optr.push_back(hoisted[r].device_data());
+        }
+        int fell_back = 0;
+        util::hip_check(moai_apply_galois_hoisted(context.device(), c.device_data(), optr.data(), L, elts.data(), kptr.data(), cptr.data(), 2, 1,
+                                                  &fell_back, context.stream()));
+        for (int r = 0; r < 2; r++)
+        {
+            Ciphertext separate;
+            evaluator.rotate_vector(c, steps[r], gk, separate);
+            CHECK(separate.download() == hoisted[r].download());
+        }
+    }
+    // above the limit: the keys that are asked come back whole, the others stay trimmed
+    CHECK(program(3) == full_high);
+    CHECK(gk.regrown_count() == 3 && rk.regrown_count() == 1); // the keys of steps 3, 8 and -1; those of 1 and 2 were not asked
+    CHECK(program(1) == full_low);
+    // without a host copy a higher level is an error, not a wrong result
+    GaloisKeys gk2;
+    keygen.create_galois_keys(vector<int>{ 1 }, gk2);
+    gk2.limit_to_chain_index(context, 0, false);
+    Ciphertext c = at_index(2), out;
+    CHECK_THROWS(evaluator.rotate_vector(c, 1, gk2, out), std::logic_error);
+    c = at_index(0);
+    evaluator.rotate_vector(c, 1, gk2, out);
+}
+
 int main()
 {
     try
@@ -721,6 +812,7 @@ int main()
         concurrent_callers();
         packed_random_program();
         regenerated_keys_and_hoisting();
+        trimmed_keys();
     }
     catch (const std::exception &e)
     {

@@ -971,3 +971,63 @@ def test_stream_audit_refuses_a_block_on_another_stream(moai):
 def octx_add(primes, a):
     q = np.array(primes, dtype=np.uint64)[None, :, None]
     return (a + a) % q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn,bits,levels", [(12, [51, 46, 46, 51, 46, 58], 3), (10, [46, 46, 51, 58], 2)])
+def test_level_trimmed_key_gives_the_oracles_bits(moai, logn, bits, levels, ks_arith):
+    """moai_key_trim: a key cut down to the digits and rows a switch at <= `levels` data primes reads (SEAL/evaluator.cpp:2818,
+    2831) gives the oracle's bits in every key-switch entry point -- apply_galois, switch_key, relinearize, the hoisted
+    rotations and their correction -- at its level and below; a higher level is refused (MOAI_ERANGE), and the full key it was
+    cut from serves that level (re-materialisation = going back to the full key)."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    k = len(primes)
+    rng = np.random.default_rng(logn + levels)
+    key = O.uniform_rns(rng, primes, (k - 1, 2), n)
+    dfull = up(moai, key)
+    dtrim = ctx.key_trim(dfull, levels)
+    assert dtrim.n_words == levels * 2 * (levels + 1) * n < dfull.n_words
+    elt = ctx.galois_elt_from_step(3)
+    for L in range(1, levels + 1):
+        ct = O.uniform_rns(rng, primes[:L], (2, 2), n)
+        want = [octx.apply_galois(ct[b], L, elt, key).reshape(2, L, n) for b in range(2)]
+        for dk in (dtrim, dfull):
+            d = up(moai, ct)
+            ctx.apply_galois(d, L, elt, dk, 2)
+            got = d.to_numpy(ct.shape)
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), L
+        # relinearize: a size-3 ciphertext with the trimmed key as the relinearization key
+        ct3 = O.uniform_rns(rng, primes[:L], (1, 3), n)
+        dout = moai.DeviceBuffer(2 * L * n)
+        ctx.relinearize(up(moai, ct3), dtrim, dout, L, 1)
+        assert (dout.to_numpy((2, L, n)) == octx.relinearize(ct3[0], L, key)).all(), L
+    # hoisted rotations with the trimmed key and a correction computed FROM the trimmed key
+    if logn >= 12:
+        L = levels
+        elts = [ctx.galois_elt_from_step(s) for s in (1, 2, 5)]
+        corr_t = [ctx.hoist_correction(dtrim, e, L) for e in elts]
+        corr_f = [ctx.hoist_correction(dfull, e, L) for e in elts]
+        for a, b in zip(corr_t, corr_f):
+            assert (a.to_numpy() == b.to_numpy()).all()
+        ct = O.uniform_rns(rng, primes[:L], (1, 2), n)
+        dct = up(moai, ct)
+        dout = moai.DeviceBuffer(3 * 2 * L * n)
+        assert not ctx.apply_galois_hoisted(dct, dout, L, elts, [dtrim, dfull, dtrim], corr_t, 1)
+        got = dout.to_numpy((3, 1, 2, L, n))
+        for r, e in enumerate(elts):
+            assert (got[r, 0] == octx.apply_galois(ct[0], L, e, key).reshape(2, L, n)).all(), r
+    # one level above what the trimmed key holds
+    if levels < k - 1:
+        L = levels + 1
+        ct = O.uniform_rns(rng, primes[:L], (1, 2), n)
+        d = up(moai, ct)
+        with pytest.raises(moai.hip.MoaiError) as e:
+            ctx.apply_galois(d, L, elt, dtrim, 1)
+        assert e.value.code == -3 and "trimmed" in str(e.value)
+        assert (d.to_numpy(ct.shape) == ct).all()  # refused before anything was enqueued
+        ctx.apply_galois(d, L, elt, dfull, 1)
+        assert (d.to_numpy(ct.shape)[0] == octx.apply_galois(ct[0], L, elt, key).reshape(2, L, n)).all()
+    # a forgotten record: the pointer is a plain key again (and too short to be one -- so only forget before freeing)
+    ctx.key_forget(dtrim)

@@ -89,7 +89,7 @@ static int usable_threads()
     return std::min(n, 32);
 }
 
-int main(int argc, char **argv)
+static int run(int argc, char **argv)
 {
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const int pack = argc > 1 ? atoi(argv[1]) : 48;
@@ -130,6 +130,14 @@ int main(int argc, char **argv)
     if (with_head)
     {
         keygen.create_galois_keys(gal_keys);
+    }
+    // The default rotation keys serve Q K^T and softmax . V only, at chain index <= 14 (Ct_ct_matrix_mul.hpp:29,95,112,147 called from
+    // single_att_block.hpp:119,197): keep on the device what those levels read -- 19 percent of 41 GB -- and park the rest in host
+    // memory (KSwitchKeys::limit_to_chain_index; a switch at a higher level would bring a key back whole, same bits either way).
+    // MOAI_KEEP_FULL_KEYS=1 leaves them whole.
+    if (!getenv("MOAI_KEEP_FULL_KEYS"))
+    {
+        gal_keys.limit_to_chain_index(context, 14);
     }
     GaloisKeys gal_keys_boot;
     Encryptor encryptor(context, public_key);
@@ -404,4 +412,21 @@ int main(int argc, char **argv)
            pack, threads, setup_s, boot_packed_ms, boot_calls_ms, boot_index, boot_err, head_s, head_err, head_err_true, slice_cols, gelu_cts,
            ffn_selfout_s, ffn_inter_s, ffn_gelu_s, ffn_final_s, ops_boot.c_str(), ops_head.c_str());
     return 0;
+}
+
+// a failure on the device (out of memory above all) is reported and ends the process with a non-zero status instead of
+// std::terminate
+int main(int argc, char **argv)
+{
+    try
+    {
+        return run(argc, argv);
+    }
+    catch (const std::exception &e)
+    {
+        size_t f = 0, t = 0;
+        moai_mem_info(&f, &t);
+        fprintf(stderr, "FAILED: %s  [device memory: %.1f GiB free of %.1f]\n", e.what(), f / 1073741824.0, t / 1073741824.0);
+        return 3;
+    }
 }

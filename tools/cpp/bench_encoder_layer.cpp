@@ -47,7 +47,7 @@ static double now_s()
     return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int main(int argc, char **argv)
+static int run(int argc, char **argv)
 {
     const int heads = argc > 1 ? atoi(argv[1]) : 12;
     const int boot_B = argc > 4 ? atoi(argv[4]) : 48; // must divide 768; 63.8 ms per bootstrap at 48, 65.6 ms at 16
@@ -75,6 +75,14 @@ int main(int argc, char **argv)
     keygen.create_relin_keys(relin_keys);
     GaloisKeys gal_keys, gal_keys_boot;
     keygen.create_galois_keys(gal_keys); // test_full_scheme.hpp: the rotation keys of the matrix products
+    // The default rotation keys serve Q K^T and softmax . V only, at chain index <= 14 (Ct_ct_matrix_mul.hpp:29,95,112,147 called from
+    // single_att_block.hpp:119,197): keep on the device what those levels read -- 19 percent of 41 GB -- and park the rest in host
+    // memory (KSwitchKeys::limit_to_chain_index; a switch at a higher level would bring a key back whole, same bits either way).
+    // MOAI_KEEP_FULL_KEYS=1 leaves them whole.
+    if (!getenv("MOAI_KEEP_FULL_KEYS"))
+    {
+        gal_keys.limit_to_chain_index(context, 14);
+    }
     vector<int> steps{ 0 };
     for (int i = 0; i < 15; i++) steps.push_back(1 << i);
     moai_fused::boot_rotation_steps_3(logn, logn, steps);
@@ -428,4 +436,21 @@ int main(int argc, char **argv)
     enc_ecd_x_copy = enc_ecd_x;
     }
     return 0;
+}
+
+// a failure on the device (out of memory above all) is reported and ends the process with a non-zero status instead of
+// std::terminate
+int main(int argc, char **argv)
+{
+    try
+    {
+        return run(argc, argv);
+    }
+    catch (const std::exception &e)
+    {
+        size_t f = 0, t = 0;
+        moai_mem_info(&f, &t);
+        fprintf(stderr, "FAILED: %s  [device memory: %.1f GiB free of %.1f]\n", e.what(), f / 1073741824.0, t / 1073741824.0);
+        return 3;
+    }
 }

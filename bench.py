@@ -294,7 +294,7 @@ def load_traffic():
 
 
 SHOUP_BFLY_PER_S = 1.716e12   # the exact 64-bit Harvey/Shoup butterfly (31 VALU instructions; 60/61-bit primes' fallback)
-LAZY8_BFLY_PER_S = 1.716e12   # the M_LAZY8 butterfly the bench's kernels run (set from the same file once measured)
+LAZY8_BFLY_PER_S = 1.887e12   # the M_LAZY8 butterfly the bench's kernels run (26 VALU instructions)
 COPY_RATE_GBS = 5280.0        # read+write rate of an in-place 32 KiB-tile kernel on this part (same file); HBM3E spec 8000
 NTT_BOUND_EVIDENCE = ("profiles/r03_ntt_pmc_summary.json: vector ALUs busy for most of both kernels' cycles, ~26 VALU instructions per "
                       "butterfly; HBM traffic 2.0 x algorithmic (two launches) would need less time than the arithmetic")

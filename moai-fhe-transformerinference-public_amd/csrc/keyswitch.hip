@@ -570,7 +570,15 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p1.L = (uint32_t)L;
     p1.G = (uint32_t)G;
     p1.total_work = (uint32_t)(batch * G * L * TPR);
-    hipLaunchKernelGGL((ks_fwd_strided<LOGN, MODE>), dim3(p1.total_work), dim3(256), 0, s, p1);
+    p1.tw1 = c->fwd_twf1;
+    if (MODE == M_FPN && tuning("MOAI_KS_P1_PRE", 0))
+    {
+        hipLaunchKernelGGL((ks_fwd_strided<LOGN, MODE, MODE == M_FPN>), dim3(p1.total_work), dim3(256), 0, s, p1);
+    }
+    else
+    {
+        hipLaunchKernelGGL((ks_fwd_strided<LOGN, MODE>), dim3(p1.total_work), dim3(256), 0, s, p1);
+    }
     MOAI_LAUNCH_CHECK();
     KsP2Args p2;
     p2.tmp = tmp;
@@ -591,7 +599,22 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p2.jchunk = (uint32_t)((L + splits - 1) / splits);
     p2.split_stride = batch * 2 * (L + 1) * c->n;
     p2.total_work = (uint32_t)(batch * G * TPR * 2 * splits); // 2048-coefficient tiles
-    hipLaunchKernelGGL((ks_contig_mac8<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
+    // where the MAC fetches its key residues (keyswitch_kernels.hip.h): all eight loads at the head of the MAC by default --
+    // same box, same hour, l = 35 / 15, batch 64: 0.572 / 0.134 ms per ciphertext with the compiler's placement (0), 0.532 / 0.121
+    // with 1, 0.547 / 0.124 with 2 (profiles/r03_b_ks_kernel_variants_ab.txt)
+    const long pf = MODE >= M_FPN ? tuning("MOAI_KS_MAC_PF", 1) : 0;
+    if (pf == 1)
+    {
+        hipLaunchKernelGGL((ks_contig_mac8<LOGN, MODE, (MODE >= M_FPN ? 1 : 0)>), dim3(p2.total_work), dim3(256), 0, s, p2);
+    }
+    else if (pf == 2)
+    {
+        hipLaunchKernelGGL((ks_contig_mac8<LOGN, MODE, (MODE >= M_FPN ? 2 : 0)>), dim3(p2.total_work), dim3(256), 0, s, p2);
+    }
+    else
+    {
+        hipLaunchKernelGGL((ks_contig_mac8<LOGN, MODE>), dim3(p2.total_work), dim3(256), 0, s, p2);
+    }
     MOAI_LAUNCH_CHECK();
     return MOAI_OK;
 }
@@ -1173,6 +1196,7 @@ static int hoist_group(moai_ctx *c, const uint64_t *t, uint64_t *tmp, const uint
     p1.t = t;
     p1.tmp = tmp;
     p1.tw = mode >= M_FPN ? c->fwd_twf : c->fwd_tw;
+    p1.tw1 = c->fwd_twf1;
     p1.pc = c->pc;
     p1.grp = grp;
     p1.L = (uint32_t)L;

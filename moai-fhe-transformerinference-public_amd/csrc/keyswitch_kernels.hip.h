@@ -25,6 +25,7 @@ struct KsP1Args
     const uint64_t *t;  // [B][L][N] digits in coefficient form
     uint64_t *tmp;      // [B][G][L][N] after the strided pass, lazy [0,4q)
     const Tw *tw;
+    const double *tw1;  // FP64 modes: the forward powers as plain doubles (PRE variant), or nullptr
     const PrimeConst *pc;
     KsGroup grp;
     uint32_t L;
@@ -38,7 +39,7 @@ struct KsP1Args
 //   M_NOGUARD  prime below 2^64/36 and 36 q^2 L < 2^128: no guards, and the unreduced digit (< 33q) goes
 //              straight into the 128-bit MAC
 //   M_FPN/FPR  prime below 2^51: FP64 butterflies (tw = the FP64 table), canonical integer into the MAC
-template <int LOGN, int MODE>
+template <int LOGN, int MODE, bool PRE = false>
 __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -71,14 +72,16 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
             op.cr1 = pc->cr1;
             op.qd = pc->qd;
             op.qinv = pc->qinv;
-            fwd_strided_tile<LOGN, LoadBarrettFp, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+            fwd_strided_tile<LOGN, LoadBarrettFp, MODE, PRE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op,
+                                                             PRE ? a.tw1 + ((size_t)prime << LOGN) : nullptr);
         }
         else
         {
             LoadFp52 op;
             op.qd = pc->qd;
             op.qinv = pc->qinv;
-            fwd_strided_tile<LOGN, LoadFp52, MODE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+            fwd_strided_tile<LOGN, LoadFp52, MODE, PRE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op,
+                                                        PRE ? a.tw1 + ((size_t)prime << LOGN) : nullptr);
         }
     }
     // digit J is canonical under prime J: it needs reducing only when that prime is the larger one
@@ -147,7 +150,12 @@ __device__ __forceinline__ uint32_t phys8_b(uint32_t e)
     return e ^ (((e >> 5) & 3u) << 1);
 }
 
-template <int LOGN, int MODE>
+// PF (FP64 modes): where the digit's sixteen key residues per thread (eight 16-byte loads) are issued.  0: next to the
+// products that use them, two loads per quarter of the MAC with a wait behind each pair -- what the compiler makes of the
+// straightforward loop (the periodic reduction's branch keeps it from moving them): four exposed L2 round trips per digit.
+// 1: all eight at the head of the MAC, one wait.  2: all eight at the head of the iteration, next to the digit's own loads,
+// so that they are in flight during the whole transform (32 more registers live across it).
+template <int LOGN, int MODE, int PF = 0>
 __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
 {
     constexpr int R1 = LOGN - 8;
@@ -220,6 +228,21 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
         const uint64_t *__restrict__ base = dig + ((size_t)J << LOGN);
         uint64_t x[8];
         const bool direct = (slot == J); // workgroup-uniform
+        const uint32_t krow = slot == a.L ? a.k - 1 : prime; // the special prime's row is the last one of the key's layout
+        const ulonglong2 *__restrict__ k0 =
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + krow) << LOGN)) + ((size_t)tile << 10) + ch0;
+        const ulonglong2 *__restrict__ k1 =
+            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + krow) << LOGN)) + ((size_t)tile << 10) + ch0;
+        ulonglong2 kpa[4], kpb[4];
+        if (MODE >= M_FPN && PF == 2)
+        {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                kpa[c] = k0[c];
+                kpb[c] = k1[c];
+            }
+        }
         if (direct)
         {
             // digit under its own prime: canonical NTT-form values straight from the target row
@@ -331,12 +354,48 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             }
         }
         } // !direct
-        const uint32_t krow = slot == a.L ? a.k - 1 : prime; // the special prime's row is the last one of the key's layout
-        const ulonglong2 *__restrict__ k0 =
-            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 0) * a.k + krow) << LOGN)) + ((size_t)tile << 10) + ch0;
-        const ulonglong2 *__restrict__ k1 =
-            reinterpret_cast<const ulonglong2 *>(a.key + (((size_t)(J * 2 + 1) * a.k + krow) << LOGN)) + ((size_t)tile << 10) + ch0;
-        if (MODE >= M_FPN)
+        if (MODE >= M_FPN && PF != 0)
+        {
+            // the same products and sums as below, in the same order per accumulator: the same bits
+            const double qd = u2d(bq1), qinv = u2d(bq2);
+            if (PF == 1)
+            {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    kpa[c] = k0[c];
+                    kpb[c] = k1[c];
+                }
+            }
+            double sm[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const double vx = fp_red(direct ? fp_from_u52(x[2 * c]) : u2d(x[2 * c]), qd, qinv);
+                const double vy = fp_red(direct ? fp_from_u52(x[2 * c + 1]) : u2d(x[2 * c + 1]), qd, qinv);
+                sm[4 * c + 0] = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kpa[c].x), qd, qinv);
+                sm[4 * c + 1] = u2d(lo0[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(kpa[c].y), qd, qinv);
+                sm[4 * c + 2] = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kpb[c].x), qd, qinv);
+                sm[4 * c + 3] = u2d(lo1[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(kpb[c].y), qd, qinv);
+            }
+            if (MODE == M_FPR || ((J - j0) & 15u) == 15u) // wave-uniform: one branch around all sixteen reductions
+            {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                {
+                    sm[i] = fp_red(sm[i], qd, qinv);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                lo0[2 * c] = d2u(sm[4 * c + 0]);
+                lo0[2 * c + 1] = d2u(sm[4 * c + 1]);
+                lo1[2 * c] = d2u(sm[4 * c + 2]);
+                lo1[2 * c + 1] = d2u(sm[4 * c + 3]);
+            }
+        }
+        else if (MODE >= M_FPN)
         {
             // FP64 modes: the MAC stays on the FP64 pipe as well.  The digit is reduced to |v| <= q/2 so that
             // h * (1/q) estimates the quotient of v * key within 0.9 (key canonical, below 2^51), each product
@@ -559,28 +618,50 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac(HoistMacArgs a)
         const uint32_t krow = slot == a.L ? a.k - 1 : prime; // a.k = rows per key polynomial in this key's layout
         const uint64_t *__restrict__ k0 = a.key + (((size_t)(J * 2 + 0) * a.k + krow) << LOGN) + obase;
         const uint64_t *__restrict__ k1 = a.key + (((size_t)(J * 2 + 1) * a.k + krow) << LOGN) + obase;
+        // all twenty-four loads of the digit first (the compiler otherwise issues them three at a time with a full wait behind
+        // each triple -- the periodic reduction's branch pins them: eight exposed round trips per digit), then the arithmetic,
+        // then ONE wave-uniform branch around the reductions.  Same operations per accumulator in the same order: same bits.
+        uint64_t xs[8], kas[8], kbs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
         {
-            const uint64_t x = row[src[e]];
-            const uint64_t ka = k0[(size_t)e << 8], kb = k1[(size_t)e << 8];
-            if (FP)
+            xs[e] = row[src[e]];
+            kas[e] = k0[(size_t)e << 8];
+            kbs[e] = k1[(size_t)e << 8];
+        }
+        if (FP)
+        {
+            double s0[8], s1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
             {
-                const double v = fp_red(fp_from_u52(x), qd, qinv);
-                double s0 = u2d(lo0[e]) + fp_mulmod_q(v, fp_from_u52(ka), qd, qinv);
-                double s1 = u2d(lo1[e]) + fp_mulmod_q(v, fp_from_u52(kb), qd, qinv);
-                if (FPR || (J & 15u) == 15u)
-                {
-                    s0 = fp_red(s0, qd, qinv);
-                    s1 = fp_red(s1, qd, qinv);
-                }
-                lo0[e] = d2u(s0);
-                lo1[e] = d2u(s1);
+                const double v = fp_red(fp_from_u52(xs[e]), qd, qinv);
+                s0[e] = u2d(lo0[e]) + fp_mulmod_q(v, fp_from_u52(kas[e]), qd, qinv);
+                s1[e] = u2d(lo1[e]) + fp_mulmod_q(v, fp_from_u52(kbs[e]), qd, qinv);
             }
-            else
+            if (FPR || (J & 15u) == 15u)
             {
-                mac128r(lo0[e], hi0[e], x, ka);
-                mac128r(lo1[e], hi1[e], x, kb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                {
+                    s0[e] = fp_red(s0[e], qd, qinv);
+                    s1[e] = fp_red(s1[e], qd, qinv);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+            {
+                lo0[e] = d2u(s0[e]);
+                lo1[e] = d2u(s1[e]);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+            {
+                mac128r(lo0[e], hi0[e], xs[e], kas[e]);
+                mac128r(lo1[e], hi1[e], xs[e], kbs[e]);
             }
         }
     }
@@ -589,6 +670,13 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac(HoistMacArgs a)
     uint64_t *__restrict__ o1 = a.acc + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN) + obase;
     const uint64_t *__restrict__ c0 = a.corr + (((size_t)0 * (a.L + 1) + slot) << LOGN) + obase;
     const uint64_t *__restrict__ c1 = a.corr + (((size_t)1 * (a.L + 1) + slot) << LOGN) + obase;
+    uint64_t cv0[8], cv1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+    {
+        cv0[e] = c0[(size_t)e << 8];
+        cv1[e] = c1[(size_t)e << 8];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
     {
@@ -603,8 +691,8 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac(HoistMacArgs a)
             r0 = barrett128(lo0[e], hi0[e], q, cr0, cr1);
             r1 = barrett128(lo1[e], hi1[e], q, cr0, cr1);
         }
-        o0[(size_t)e << 8] = csub(r0 + c0[(size_t)e << 8], q);
-        o1[(size_t)e << 8] = csub(r1 + c1[(size_t)e << 8], q);
+        o0[(size_t)e << 8] = csub(r0 + cv0[e], q);
+        o1[(size_t)e << 8] = csub(r1 + cv1[e], q);
     }
 }
 
@@ -674,18 +762,33 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac2(HoistMac2Args a)
                 const uint32_t kr = a.krows[r], krow = slot == a.L ? kr - 1 : prime;
                 const uint64_t *__restrict__ k0 = a.key[r] + (((size_t)(J * 2 + 0) * kr + krow) << LOGN);
                 const uint64_t *__restrict__ k1 = a.key[r] + (((size_t)(J * 2 + 1) * kr + krow) << LOGN);
+                // this rotation's key residues first, then the products, then one wave-uniform branch around the reductions
+                // (see ks_hoisted_mac): same operations per accumulator in the same order
+                uint64_t ka[E], kb[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e)
                 {
-                    double t0 = s0[r][e] + fp_mulmod_q(v[e], fp_from_u52(k0[dst[r][e]]), qd, qinv);
-                    double t1 = s1[r][e] + fp_mulmod_q(v[e], fp_from_u52(k1[dst[r][e]]), qd, qinv);
-                    if (FPR || (J & 15u) == 15u)
+                    ka[e] = k0[dst[r][e]];
+                    kb[e] = k1[dst[r][e]];
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                {
+                    s0[r][e] += fp_mulmod_q(v[e], fp_from_u52(ka[e]), qd, qinv);
+                    s1[r][e] += fp_mulmod_q(v[e], fp_from_u52(kb[e]), qd, qinv);
+                }
+            }
+            if (FPR || (J & 15u) == 15u)
+            {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
                     {
-                        t0 = fp_red(t0, qd, qinv);
-                        t1 = fp_red(t1, qd, qinv);
+                        s0[r][e] = fp_red(s0[r][e], qd, qinv);
+                        s1[r][e] = fp_red(s1[r][e], qd, qinv);
                     }
-                    s0[r][e] = t0;
-                    s1[r][e] = t1;
                 }
             }
         }

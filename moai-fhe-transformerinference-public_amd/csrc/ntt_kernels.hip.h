@@ -173,10 +173,15 @@ __device__ __forceinline__ void ct_bfly_stage(uint64_t &x, uint64_t &y, uint64_t
 }
 
 // one tile of the strided pass: reads row `inp`, writes row `outp` (may be the same row)
-template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD>
+// PRE (FP64 modes, with tw1 = the forward powers as plain doubles): the per-thread twiddles of phase B -- fifteen at N = 2^16 --
+// are fetched as 8-byte doubles BEFORE the exchange instead of as 16-byte {w, w/q} pairs one or two at a time between the
+// butterflies that use them (ten exposed round trips to L2 per tile in the compiled loop); the butterflies then take their
+// quotient estimate from RN(y w) RN(1/q) like the contiguous key-switch pass (ct_bfly_fp1: growth below 2q per stage instead of
+// 0.75q; 46-bit primes still end all sixteen stages below 28q < 2^52).  Same residues.
+template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD, bool PRE = false>
 __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
                                                  const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
-                                                 const uint32_t tid, LoadOp op = LoadOp())
+                                                 const uint32_t tid, LoadOp op = LoadOp(), const double *__restrict__ tw1 = nullptr)
 {
     constexpr int R1 = LOGN - 8;
     constexpr int RB = R1 - 4;
@@ -209,6 +214,21 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
     }
     if (RB > 0)
     {
+        double twb[16];
+        if (PRE)
+        {
+            const uint32_t thp = tid >> GB;
+#pragma unroll
+            for (int s = 4; s < R1; ++s)
+            {
+                const int cnt = 16 >> (R1 - s); // distinct twiddles of this stage per thread
+#pragma unroll
+                for (int i = 0; i < cnt; ++i)
+                {
+                    twb[cnt - 1 + i] = tw1[(1u << s) + ((thp << (4 - (R1 - s))) | (uint32_t)i)];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j)
         {
@@ -232,9 +252,16 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
             {
                 if (!(j & half))
                 {
-                    uint32_t t_ = (th << 4) | (uint32_t)j;
-                    Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
-                    ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - s);
+                    if (PRE)
+                    {
+                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], twb[(16 >> (R1 - s)) - 1 + (j >> (R1 - s))], u2d(q), u2d(q2));
+                    }
+                    else
+                    {
+                        uint32_t t_ = (th << 4) | (uint32_t)j;
+                        Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
+                        ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - s);
+                    }
                 }
             }
         }

@@ -1002,7 +1002,7 @@ def test_level_trimmed_key_gives_the_oracles_bits(moai, logn, bits, levels, ks_a
         ct3 = O.uniform_rns(rng, primes[:L], (1, 3), n)
         dout = moai.DeviceBuffer(2 * L * n)
         ctx.relinearize(up(moai, ct3), dtrim, dout, L, 1)
-        assert (dout.to_numpy((2, L, n)) == octx.relinearize(ct3[0], L, key)).all(), L
+        assert (dout.to_numpy((2, L, n)) == octx.relinearize(ct3[0], key, L)).all(), L
     # hoisted rotations with the trimmed key and a correction computed FROM the trimmed key
     if logn >= 12:
         L = levels

@@ -2,7 +2,7 @@
 # PMC passes over a python program (rocprofv3 --pmc only; never combined with trace domains other than kernel-trace),
 # then one --kernel-trace --stats pass.  usage: tools/pmc.sh <tag> <script.py> [args]   (default: bench.py, NTT only)
 tag=$1; shift
-if [ $# -eq 0 ]; then set -- bench.py --no-cpu-baseline --no-e2e --steps 2 --warmup 1; fi
+if [ $# -eq 0 ]; then set -- bench.py --no-cpu-baseline --no-e2e --no-keyswitch --steps 2 --warmup 1; fi
 prog=$GRAFT_REPO_ROOT/$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out

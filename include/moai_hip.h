@@ -127,6 +127,20 @@ int moai_mul_scalar_rows(moai_ctx *ctx, const uint64_t *a, const uint64_t *scala
 int moai_add_scalar_rows(moai_ctx *ctx, const uint64_t *a, const uint64_t *scalars, uint64_t *out, size_t n_poly,
                          size_t L, void *stream);
 
+/* out = base + sum_{t < terms} x[t] (*) scalars[t]   -- the accumulation chain of MOAI's column-packed ct x pt product
+ * (include/source/matrix_mul/Ct_pt_matrix_mul.hpp:19-42: Evaluator::multiply_plain by a scalar-encoded plaintext,
+ * SEAL/evaluator.cpp:2336-2373 with SEAL/ckks.cpp:131-150, then Evaluator::add_inplace, :155-240, once per row of W) as one
+ * pass per sixteen terms.  x: HOST array of `terms` device pointers, each [size][L][N]; scalars: HOST [terms][L], the plaintexts'
+ * constant rows, reduced; base: device [size][L][N] or NULL (may be `out`); out: device [size][L][N], not one of the terms.
+ * Canonical residues out: the same bits as the reference's `terms` products and sums. */
+int moai_scalar_dot(moai_ctx *ctx, const uint64_t *const *x, const uint64_t *scalars, size_t terms, const uint64_t *base,
+                    uint64_t *out, size_t size, size_t L, void *stream);
+/* The same chain with full plaintexts (MOAI's masked products, Ct_pt_matrix_mul.hpp:103-170: multiply_plain_ntt's dyadic
+ * product, SEAL/evaluator.cpp:2336-2373, then add_inplace): out = base + sum_t x[t] (*) p[t].  x: HOST array of device
+ * pointers as above; p: DEVICE [terms][L][N], the plaintexts back to back in NTT form (moai_ckks_encode_masked writes them so). */
+int moai_vector_dot(moai_ctx *ctx, const uint64_t *const *x, const uint64_t *p, size_t terms, const uint64_t *base, uint64_t *out,
+                    size_t size, size_t L, void *stream);
+
 /* ---- ciphertext products -------------------------------------------------------------------------
  * Evaluator::ckks_multiply SEAL/evaluator.cpp:770-909, size 2 x size 2 -> size 3:
  * out[b] = (x0*y0, x0*y1 + x1*y0, x1*y1).  x, y: [batch][2][L][N]; out: [batch][3][L][N]

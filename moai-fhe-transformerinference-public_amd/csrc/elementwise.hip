@@ -112,6 +112,131 @@ __global__ __launch_bounds__(256) void scalar_rows_kernel(ScalarArgs g)
     }
 }
 
+// out = base + sum_t x[t] (*) s[t]   (one scalar per term and RNS row): the accumulation chain of MOAI's column-packed ct x pt
+// product -- multiply_plain by a scalar plaintext, add_inplace, 768 times per output column (Ct_pt_matrix_mul.hpp:19-42) --
+// for up to SCALAR_DOT_TERMS terms per launch, pointers and scalars in the kernel arguments (nothing staged through memory)
+constexpr int SCALAR_DOT_TERMS = 16;
+constexpr int SCALAR_DOT_WORDS = 432; // 16 terms x 27 rows; fewer terms per launch above 27 rows
+struct ScalarDotArgs
+{
+    const uint64_t *x[SCALAR_DOT_TERMS]; // each [size][L][N]
+    const uint64_t *base;                // [size][L][N] or nullptr
+    uint64_t *out;                       // may be `base`
+    const PrimeConst *pc;
+    uint32_t L, n2, terms;
+    uint64_t s[SCALAR_DOT_WORDS];        // [terms][L], canonical residues
+};
+
+__global__ __launch_bounds__(256) void scalar_dot_kernel(ScalarDotArgs g)
+{
+    const uint32_t row = blockIdx.y; // poly * L + prime
+    const uint32_t prime = row % g.L;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const ulonglong2 *b2 = g.base ? reinterpret_cast<const ulonglong2 *>(g.base) + (size_t)row * g.n2 : nullptr;
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)row * g.n2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        // sixteen products below 2^122 on top of a base below 2^61: no overflow of the 128-bit sums
+        uint64_t lx = 0, hx = 0, ly = 0, hy = 0;
+        if (b2)
+        {
+            const ulonglong2 b = b2[i];
+            lx = b.x;
+            ly = b.y;
+        }
+        ulonglong2 v[SCALAR_DOT_TERMS];
+#pragma unroll
+        for (int t = 0; t < SCALAR_DOT_TERMS; ++t)
+        {
+            if ((uint32_t)t < g.terms)
+            {
+                v[t] = (reinterpret_cast<const ulonglong2 *>(g.x[t]) + (size_t)row * g.n2)[i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SCALAR_DOT_TERMS; ++t)
+        {
+            if ((uint32_t)t < g.terms)
+            {
+                const uint64_t sc = g.s[(uint32_t)t * g.L + prime];
+                uint64_t pl = v[t].x * sc, ph = mulhi64(v[t].x, sc);
+                lx += pl;
+                hx += ph + (lx < pl ? 1 : 0);
+                pl = v[t].y * sc;
+                ph = mulhi64(v[t].y, sc);
+                ly += pl;
+                hy += ph + (ly < pl ? 1 : 0);
+            }
+        }
+        ulonglong2 r;
+        r.x = barrett128(lx, hx, q, cr0, cr1);
+        r.y = barrett128(ly, hy, q, cr0, cr1);
+        o2[i] = r;
+    }
+}
+
+// out = base + sum_t x[t] (*) p[t]  with full plaintexts p[t] [L][N] back to back: the accumulation chain of MOAI's MASKED ct x pt
+// products (vector-encoded weights, Ct_pt_matrix_mul.hpp:103-170) over ciphertexts that sit in separate blocks
+struct VectorDotArgs
+{
+    const uint64_t *x[SCALAR_DOT_TERMS]; // each [size][L][N]
+    const uint64_t *p;                   // [terms][L][N]
+    const uint64_t *base;
+    uint64_t *out;
+    const PrimeConst *pc;
+    uint32_t L, n2, terms;
+};
+
+__global__ __launch_bounds__(256) void vector_dot_kernel(VectorDotArgs g)
+{
+    const uint32_t row = blockIdx.y; // poly * L + prime
+    const uint32_t prime = row % g.L;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const ulonglong2 *b2 = g.base ? reinterpret_cast<const ulonglong2 *>(g.base) + (size_t)row * g.n2 : nullptr;
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(g.out) + (size_t)row * g.n2;
+    const ulonglong2 *p2 = reinterpret_cast<const ulonglong2 *>(g.p) + (size_t)prime * g.n2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        uint64_t lx = 0, hx = 0, ly = 0, hy = 0;
+        if (b2)
+        {
+            const ulonglong2 b = b2[i];
+            lx = b.x;
+            ly = b.y;
+        }
+        ulonglong2 v[SCALAR_DOT_TERMS], w[SCALAR_DOT_TERMS];
+#pragma unroll
+        for (int t = 0; t < SCALAR_DOT_TERMS; ++t)
+        {
+            if ((uint32_t)t < g.terms)
+            {
+                v[t] = (reinterpret_cast<const ulonglong2 *>(g.x[t]) + (size_t)row * g.n2)[i];
+                w[t] = p2[(size_t)t * g.L * g.n2 + i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SCALAR_DOT_TERMS; ++t)
+        {
+            if ((uint32_t)t < g.terms)
+            {
+                uint64_t pl = v[t].x * w[t].x, ph = mulhi64(v[t].x, w[t].x);
+                lx += pl;
+                hx += ph + (lx < pl ? 1 : 0);
+                pl = v[t].y * w[t].y;
+                ph = mulhi64(v[t].y, w[t].y);
+                ly += pl;
+                hy += ph + (ly < pl ? 1 : 0);
+            }
+        }
+        ulonglong2 r;
+        r.x = barrett128(lx, hx, q, cr0, cr1);
+        r.y = barrett128(ly, hy, q, cr0, cr1);
+        o2[i] = r;
+    }
+}
+
 struct CtMulArgs
 {
     const uint64_t *x; // [batch][2][L][N]
@@ -898,6 +1023,123 @@ extern "C" int moai_mul_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64
     MOAI_AUDIT(stream, a, scalars, out);
     trace_op("mul_scalar_rows", L, n_poly);
     return scalar_rows(c, a, scalars, out, n_poly, L, stream, true);
+}
+
+extern "C" int moai_scalar_dot(moai_ctx *c, const uint64_t *const *x, const uint64_t *scalars, size_t terms, const uint64_t *base,
+                               uint64_t *out, size_t size, size_t L, void *stream)
+{
+    MOAI_AUDIT(stream, base, out);
+    for (size_t t = 0; x && t < terms; ++t)
+    {
+        MOAI_AUDIT(stream, x[t]);
+    }
+    trace_op("ct_pt_dot", L, terms * size); // what the reference does per term: multiply_plain + add_inplace
+    int rc = check_rows(c, size, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (size == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!out || (terms && (!x || !scalars)))
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    for (size_t t = 0; t < terms; ++t)
+    {
+        if (!x[t] || x[t] == out)
+        {
+            return set_error(MOAI_EINVAL, "null term, or a term that is the output");
+        }
+        for (size_t r = 0; r < L; ++r)
+        {
+            if (scalars[t * L + r] >= c->primes[r])
+            {
+                return set_error(MOAI_EINVAL, "scalar not reduced modulo its prime");
+            }
+        }
+    }
+    const size_t per = std::min<size_t>(SCALAR_DOT_TERMS, SCALAR_DOT_WORDS / L);
+    MOAI_CHECK_GRID_ROWS(size * L);
+    size_t t0 = 0;
+    do
+    {
+        const size_t cnt = std::min(per, terms - t0);
+        ScalarDotArgs g;
+        for (size_t t = 0; t < (size_t)SCALAR_DOT_TERMS; ++t)
+        {
+            g.x[t] = t < cnt ? x[t0 + t] : nullptr;
+        }
+        g.base = t0 == 0 ? base : out;
+        g.out = out;
+        g.pc = c->pc;
+        g.L = (uint32_t)L;
+        g.n2 = (uint32_t)(c->n >> 1);
+        g.terms = (uint32_t)cnt;
+        for (size_t w = 0; w < cnt * L; ++w)
+        {
+            g.s[w] = scalars[t0 * L + w];
+        }
+        hipLaunchKernelGGL(scalar_dot_kernel, row_grid(c, size * L), dim3(256), 0, (hipStream_t)stream, g);
+        MOAI_LAUNCH_CHECK();
+        t0 += cnt;
+    } while (t0 < terms);
+    return MOAI_OK;
+}
+
+extern "C" int moai_vector_dot(moai_ctx *c, const uint64_t *const *x, const uint64_t *p, size_t terms, const uint64_t *base, uint64_t *out,
+                               size_t size, size_t L, void *stream)
+{
+    MOAI_AUDIT(stream, p, base, out);
+    for (size_t t = 0; x && t < terms; ++t)
+    {
+        MOAI_AUDIT(stream, x[t]);
+    }
+    trace_op("ct_pt_dot", L, terms * size);
+    int rc = check_rows(c, size, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (size == 0 || L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!out || (terms && (!x || !p)))
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    for (size_t t = 0; t < terms; ++t)
+    {
+        if (!x[t] || x[t] == out)
+        {
+            return set_error(MOAI_EINVAL, "null term, or a term that is the output");
+        }
+    }
+    MOAI_CHECK_GRID_ROWS(size * L);
+    size_t t0 = 0;
+    do
+    {
+        const size_t cnt = std::min<size_t>(SCALAR_DOT_TERMS, terms - t0);
+        VectorDotArgs g;
+        for (size_t t = 0; t < (size_t)SCALAR_DOT_TERMS; ++t)
+        {
+            g.x[t] = t < cnt ? x[t0 + t] : nullptr;
+        }
+        g.p = p + t0 * L * c->n;
+        g.base = t0 == 0 ? base : out;
+        g.out = out;
+        g.pc = c->pc;
+        g.L = (uint32_t)L;
+        g.n2 = (uint32_t)(c->n >> 1);
+        g.terms = (uint32_t)cnt;
+        hipLaunchKernelGGL(vector_dot_kernel, row_grid(c, size * L), dim3(256), 0, (hipStream_t)stream, g);
+        MOAI_LAUNCH_CHECK();
+        t0 += cnt;
+    } while (t0 < terms);
+    return MOAI_OK;
 }
 
 extern "C" int moai_add_scalar_rows(moai_ctx *c, const uint64_t *a, const uint64_t *scalars, uint64_t *out,

@@ -76,6 +76,8 @@ SYMBOLS = {
     "moai_mem_info": (C.c_int, [C.POINTER(sz), C.POINTER(sz)]),
     "moai_op_trace": (C.c_int, [C.c_int]),
     "moai_op_trace_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "moai_scalar_dot": (C.c_int, [vp, C.POINTER(vp), u64p, sz, vp, vp, sz, sz, vp]),
+    "moai_vector_dot": (C.c_int, [vp, C.POINTER(vp), vp, sz, vp, vp, sz, sz, vp]),
     "moai_key_words": (sz, [vp, sz]),
     "moai_key_trim": (C.c_int, [vp, vp, sz, vp, vp]),
     "moai_key_forget": (C.c_int, [vp, vp]),
@@ -318,6 +320,19 @@ class Context:
 
     def apply_galois_to(self, src, dst, L, elt, key, batch, stream=None):
         _check(lib().moai_apply_galois_to(self.h, _ptr(src), _ptr(dst), L, int(elt), _ptr(key), batch, stream))
+
+    def scalar_dot(self, xs, scalars, base, out, size, L, stream=None):
+        """out = base + sum_t xs[t] (*) scalars[t] (scalars: numpy uint64 [terms][L], reduced)"""
+        T = len(xs)
+        arr = (vp * T)(*[_ptr(x) for x in xs])
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64)
+        _check(lib().moai_scalar_dot(self.h, arr, sc.ctypes.data_as(u64p), T, _ptr(base), _ptr(out), size, L, stream))
+
+    def vector_dot(self, xs, plains, base, out, size, L, stream=None):
+        """out = base + sum_t xs[t] (*) plains[t] (plains: one device buffer [terms][L][N])"""
+        T = len(xs)
+        arr = (vp * T)(*[_ptr(x) for x in xs])
+        _check(lib().moai_vector_dot(self.h, arr, _ptr(plains), T, _ptr(base), _ptr(out), size, L, stream))
 
     def key_trim(self, full_key, levels, stream=None):
         """the part of a key a switch at <= `levels` data primes reads, as a DeviceBuffer [levels][2][levels+1][N] whose layout the

@@ -113,6 +113,7 @@ public:
 
     inline void set_final_scale(double _final_scale)
     {
+        std::lock_guard<std::mutex> run(run_mu_); // not while a bootstrap holds a reference to the engine
         final_scale = _final_scale;
         std::lock_guard<std::mutex> g(engine_mu_);
         engine_.reset();
@@ -138,6 +139,7 @@ public:
     }
     void change_logn(long new_logn)
     {
+        std::lock_guard<std::mutex> run(run_mu_); // not while a bootstrap holds a reference to the engine
         logn = new_logn;
         n = (1 << logn);
         select_slot_index();
@@ -235,6 +237,7 @@ public:
     // how the calls of this object were grouped so far: {packed runs, ciphertexts}
     std::pair<std::size_t, std::size_t> gather_statistics() const
     {
+        std::lock_guard<std::mutex> run(run_mu_);
         return { runs_, members_ };
     }
 
@@ -411,10 +414,24 @@ private:
             std::vector<Request *> batch(pending_.begin(), pending_.begin() + static_cast<std::ptrdiff_t>(take));
             pending_.erase(pending_.begin(), pending_.begin() + static_cast<std::ptrdiff_t>(take));
             lk.unlock();
-            run_batch(batch);
+            // whatever happens in the run (an allocation that fails outside the groups' own try blocks included), the batch is
+            // marked done and the queue is woken: no caller may sleep for ever behind a leader that left with an exception
+            std::exception_ptr run_error;
+            try
+            {
+                run_batch(batch);
+            }
+            catch (...)
+            {
+                run_error = std::current_exception();
+            }
             lk.lock();
             for (Request *r : batch)
             {
+                if (run_error && !r->error)
+                {
+                    r->error = run_error;
+                }
                 r->done = true;
             }
             leader_active_ = false;
@@ -487,7 +504,7 @@ private:
         }
     }
 
-    std::mutex engine_mu_, run_mu_, gather_mu_;
+    mutable std::mutex engine_mu_, run_mu_, gather_mu_;
     std::condition_variable gather_cv_;
     std::vector<Request *> pending_;
     bool leader_active_ = false;

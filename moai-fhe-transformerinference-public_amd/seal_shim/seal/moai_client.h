@@ -460,6 +460,16 @@ namespace seal
             const double bound = scale * max_abs * (1.0 + 1e-9);
             const bool conclusive = std::isfinite(bound) && static_cast<int>(std::ceil(std::log2(std::max<>(bound, 1.0)))) + 1 <
                                                                 cd->total_coeff_modulus_bit_count();
+            // a full vector with one non-zero value at some slots and zero elsewhere -- MOAI's masked weights and biases
+            // (Ct_pt_matrix_mul.hpp:124-146, single_att_block.hpp:33-42): recorded, not transformed (Plaintext::mask_).  Only when
+            // the range check above cannot fail, so that every exception of the reference is still raised here and now.
+            if (!is_complex && conclusive && count == slots_ && masked_constants_enabled())
+            {
+                if (record_masked_constant(reinterpret_cast<const double *>(values), count, parms_id, scale, L, n, destination))
+                {
+                    return;
+                }
+            }
             util::DeviceArray staging(words + 1, stream); // values, then max |coefficient|
             StagingSlot &slot = staging_slot(words * 8);
             if (words)
@@ -496,6 +506,83 @@ namespace seal
             }
             destination.parms_id_ = parms_id;
             destination.scale_ = scale;
+        }
+
+        static bool masked_constants_enabled()
+        {
+            static const bool on = [] {
+                const char *e = std::getenv("MOAI_SHIM_LAZY");
+                return !(e && e[0] == '0');
+            }();
+            return on;
+        }
+        // values = c * mask with mask in {0, 1}^slots and c != 0?  Then the plaintext records (mask, c, scale).  The mask's device
+        // copy is shared by every plaintext with the same pattern this thread encodes in a row (MOAI encodes thousands per mask).
+        bool record_masked_constant(const double *values, std::size_t count, parms_id_type parms_id, double scale, std::size_t L, std::size_t n,
+                                    Plaintext &destination) const
+        {
+            double c = 0;
+            std::size_t first = count;
+            for (std::size_t i = 0; i < count; i++)
+            {
+                if (values[i] != 0.0)
+                {
+                    c = values[i];
+                    first = i;
+                    break;
+                }
+            }
+            if (first == count || !std::isfinite(c))
+            {
+                return false; // all zero (the reference encodes that too; rare): the ordinary path
+            }
+            static thread_local std::shared_ptr<const util::SlotMask> last;
+            static thread_local moai_ctx *last_dev = nullptr;
+            const bool try_last = last && last_dev == context_.device() && last->host.size() == count;
+            bool same = try_last;
+            for (std::size_t i = 0; i < count; i++)
+            {
+                const double v = values[i];
+                if (v != 0.0 && v != c)
+                {
+                    return false; // a general vector
+                }
+                if (same && (v != 0.0) != (last->host[i] != 0))
+                {
+                    same = false;
+                }
+            }
+            if (!same)
+            {
+                auto m = std::make_shared<util::SlotMask>();
+                m->host.resize(count);
+                for (std::size_t i = 0; i < count; i++)
+                {
+                    m->host[i] = values[i] != 0.0 ? 1 : 0;
+                }
+                m->dev = std::make_shared<util::DeviceArray>((count + 1) / 2, context_.stream());
+                util::hip_check(moai_memcpy_h2d(m->dev->get(), m->host.data(), count * 4, context_.stream()));
+                context_.sync(); // once per new pattern
+                last = m;
+                last_dev = context_.device();
+            }
+            destination.scalar_rows_.clear();
+            destination.data_.release();
+            destination.n_ = n;
+            destination.L_ = L;
+            destination.stream_ = context_.stream();
+            destination.dev_ = context_.device();
+            destination.parms_id_ = parms_id;
+            destination.scale_ = scale;
+            {
+                std::lock_guard<std::mutex> g(util::lazy_mutex());
+                destination.mask_ = last;
+                destination.mask_c_ = c;
+                destination.mask_scale_ = scale;
+                destination.mask_L_ = L;
+                destination.owed_.v.store(true, std::memory_order_release);
+            }
+            return true;
         }
 
         // page-locked staging buffers for the values of vector encodes: a small ring per host thread; a slot is
@@ -728,6 +815,7 @@ namespace seal
                                             context_.stream()));
             destination.keys_.assign(1, nullptr);
             destination.hoist_ = std::make_shared<KSwitchKeys::HoistCache>(); // constants derived from the keys this call replaces
+            destination.generation_ = KSwitchKeys::next_generation();
             destination.keys_[0] = make_kswitch_key(s2.get());
             destination.parms_id_ = context_.key_parms_id();
             context_.sync();
@@ -744,6 +832,7 @@ namespace seal
             // object that already served hoisted rotations must not leave the old keys' constants behind.  A copy made earlier
             // keeps the old keys together with the old cache; copies made from now on share the new one.
             destination.hoist_ = std::make_shared<KSwitchKeys::HoistCache>();
+            destination.generation_ = KSwitchKeys::next_generation();
             util::DeviceArray rotated(k_ * n_, context_.stream());
             for (std::uint32_t elt : galois_elts)
             {

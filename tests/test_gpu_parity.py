@@ -1031,3 +1031,66 @@ def test_level_trimmed_key_gives_the_oracles_bits(moai, logn, bits, levels, ks_a
         assert (d.to_numpy(ct.shape)[0] == octx.apply_galois(ct[0], L, elt, key).reshape(2, L, n)).all()
     # a forgotten record: the pointer is a plain key again (and too short to be one -- so only forget before freeing)
     ctx.key_forget(dtrim)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn,bits,L,terms", [(12, [51, 46, 46, 58], 3, 37), (10, [60, 61, 46], 3, 16), (13, [46] * 30 + [58], 30, 25)])
+def test_scalar_dot_is_the_chain_of_multiply_plain_and_add(moai, logn, bits, L, terms):
+    """moai_scalar_dot against the oracle's chain out = x_0 * s_0; out += x_t * s_t (Evaluator::multiply_plain with a scalar-encoded
+    plaintext + add_inplace, Ct_pt_matrix_mul.hpp:19-42), bit for bit: term counts that are not a multiple of the sixteen per launch,
+    more than 27 rows (fewer terms per launch), 60/61-bit primes, edge scalars 0 and q - 1, with and without a base, in place."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    rng = np.random.default_rng(terms)
+    xs = [O.uniform_rns(rng, primes[:L], (2,), n) for _ in range(terms)]
+    sc = np.stack([np.array([int(rng.integers(0, q)) for q in primes[:L]], dtype=np.uint64) for _ in range(terms)])
+    sc[0, :] = 0
+    sc[1, :] = np.array([q - 1 for q in primes[:L]], dtype=np.uint64)
+    q = np.array(primes[:L], dtype=object)[None, :, None]
+    want = np.zeros((2, L, n), dtype=object)
+    for t in range(terms):
+        want = (want + xs[t].astype(object) * sc[t].astype(object)[None, :, None]) % q
+    dxs = [up(moai, x) for x in xs]
+    dout = moai.DeviceBuffer(2 * L * n)
+    ctx.scalar_dot(dxs, sc, None, dout, 2, L)
+    assert (dout.to_numpy((2, L, n)).astype(object) == want).all()
+    # the oracle's own multiply_plain / add chain on the first polynomial row agrees with the big-integer sum
+    pt = np.broadcast_to(sc[2][:, None], (L, n)).astype(np.uint64).copy()
+    assert (octx.multiply_plain(xs[2], 2, L, pt).astype(object) == (xs[2].astype(object) * sc[2].astype(object)[None, :, None]) % q).all()
+    # with a base, accumulating in place
+    base = O.uniform_rns(rng, primes[:L], (2,), n)
+    dacc = up(moai, base)
+    ctx.scalar_dot(dxs, sc, dacc, dacc, 2, L)
+    assert (dacc.to_numpy((2, L, n)).astype(object) == (want + base.astype(object)) % q).all()
+    with pytest.raises(moai.hip.MoaiError):
+        ctx.scalar_dot([dacc], sc[:1], None, dacc, 2, L)  # a term must not be the output
+    bad = sc[:1].copy()
+    bad[0, 0] = primes[0]
+    with pytest.raises(moai.hip.MoaiError):
+        ctx.scalar_dot(dxs[:1], bad, None, dout, 2, L)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn,bits,L,terms", [(12, [51, 46, 58], 2, 21), (11, [60, 61, 46, 46], 4, 33)])
+def test_vector_dot_is_the_chain_of_dyadic_products_and_adds(moai, logn, bits, L, terms):
+    """moai_vector_dot: out = base + sum_t x_t (*) p_t against the oracle's multiply_plain + add chain (MOAI's masked products,
+    Ct_pt_matrix_mul.hpp:103-170), bit for bit, term counts off the sixteen per launch, with a base, in place."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    rng = np.random.default_rng(terms + L)
+    xs = [O.uniform_rns(rng, primes[:L], (2,), n) for _ in range(terms)]
+    ps = O.uniform_rns(rng, primes[:L], (terms,), n)
+    want = octx.multiply_plain(xs[0], 2, L, ps[0])
+    for t in range(1, terms):
+        want = octx.add(want, octx.multiply_plain(xs[t], 2, L, ps[t]), 2, L)
+    dxs = [up(moai, x) for x in xs]
+    dp = up(moai, ps)
+    dout = moai.DeviceBuffer(2 * L * n)
+    ctx.vector_dot(dxs, dp, None, dout, 2, L)
+    assert (dout.to_numpy((2, L, n)) == np.asarray(want).reshape(2, L, n)).all()
+    base = O.uniform_rns(rng, primes[:L], (2,), n)
+    dacc = up(moai, base)
+    ctx.vector_dot(dxs, dp, dacc, dacc, 2, L)
+    assert (dacc.to_numpy((2, L, n)) == np.asarray(octx.add(base, want, 2, L)).reshape(2, L, n)).all()

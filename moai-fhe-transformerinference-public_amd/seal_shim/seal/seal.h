@@ -702,6 +702,44 @@ namespace seal
             static std::mutex m;
             return m;
         }
+        // Small host -> device copies whose source must be free again when the call returns (a constant, a few hundred of them):
+        // through a per-thread ring of page-locked slots; a slot is reused only after the event recorded behind its last copy
+        // has completed, so nobody synchronises the stream for eight bytes.
+        inline void upload_small(void *dst, const void *src, std::size_t bytes, void *stream)
+        {
+            struct Slot
+            {
+                void *host = nullptr;
+                std::size_t bytes = 0;
+                void *event = nullptr;
+                bool pending = false;
+            };
+            static thread_local Slot ring[8];
+            static thread_local unsigned next = 0;
+            Slot &sl = ring[next++ & 7u];
+            if (sl.pending)
+            {
+                hip_check(moai_event_synchronize(sl.event));
+                sl.pending = false;
+            }
+            if (!sl.event)
+            {
+                hip_check(moai_event_create(&sl.event));
+            }
+            if (sl.bytes < bytes)
+            {
+                if (sl.host)
+                {
+                    hip_check(moai_host_free(sl.host));
+                }
+                sl.bytes = std::max<std::size_t>(bytes, std::size_t(1) << 14);
+                hip_check(moai_host_malloc(&sl.host, sl.bytes));
+            }
+            std::memcpy(sl.host, src, bytes);
+            hip_check(moai_memcpy_h2d(dst, sl.host, bytes, stream));
+            hip_check(moai_event_record(sl.event, stream));
+            sl.pending = true;
+        }
         // the 0/1 slot pattern of MOAI's masked plaintexts (its bias_vec, Batch_encode_encrypt.hpp:40-49) on host and device
         struct SlotMask
         {
@@ -1261,11 +1299,11 @@ namespace seal
             data_.resize(full_L * n_, stream_);
             util::DeviceArray staging(2, stream_);
             const double c = mask_c_;
-            util::hip_check(moai_memcpy_h2d(staging.get(), &c, 8, stream_));
+            util::upload_small(staging.get(), &c, 8, stream_);
             util::hip_check(moai_ckks_encode_masked(dev_, reinterpret_cast<const double *>(staging.get()),
                                                     reinterpret_cast<const std::int32_t *>(mask_->dev->get()), mask_->host.size(), 1, data_.get(),
                                                     full_L, nullptr, mask_scale_, nullptr, stream_));
-            util::hip_check(moai_stream_sync(stream_)); // `c` and the staging block
+            mask_keep_ = mask_; // the kernel reads the mask's device copy in stream order; this object may outlive its last other owner
             mask_.reset();
             owed_.v.store(false, std::memory_order_release);
         }
@@ -1275,6 +1313,7 @@ namespace seal
         std::vector<std::uint64_t> scalar_rows_;
         mutable util::DeviceArray data_;
         mutable std::shared_ptr<const util::SlotMask> mask_; // set: the residues are owed
+        mutable std::shared_ptr<const util::SlotMask> mask_keep_;
         mutable double mask_c_ = 0, mask_scale_ = 0;         // the constant, and the scale the vector was encoded at
         std::size_t mask_L_ = 0;                               // primes at encode time (a later mod switch only drops rows)
         mutable util::CopyableFlag owed_;
@@ -1519,8 +1558,6 @@ namespace seal
             // scale -> their transforms in one moai_ckks_encode_masked call per chunk, then moai_vector_dot
             const std::uint64_t *base = buf_ ? buf_->get() : nullptr;
             const std::vector<LazyTerm> &terms = *lazy_;
-            bool must_sync = false;
-            std::vector<std::vector<double>> keep_constants; // host sources of asynchronous copies, alive until the sync below
             for (std::size_t i = 0; i < terms.size();)
             {
                 std::vector<const std::uint64_t *> ptrs;
@@ -1538,8 +1575,7 @@ namespace seal
                 else
                 {
                     const std::size_t chunk = std::max<std::size_t>(16, (std::size_t(1) << 30) / (L_ * n_ * 8));
-                    keep_constants.emplace_back();
-                    std::vector<double> &cs = keep_constants.back();
+                    std::vector<double> cs;
                     for (; j < terms.size() && j - i < chunk && terms[j].mask == terms[i].mask && terms[j].pscale == terms[i].pscale; j++)
                     {
                         ptrs.push_back(terms[j].src->get());
@@ -1547,19 +1583,14 @@ namespace seal
                     }
                     const std::size_t T = ptrs.size();
                     util::DeviceArray dconst(T, stream_), dP(T * L_ * n_, stream_);
-                    util::hip_check(moai_memcpy_h2d(dconst.get(), cs.data(), T * 8, stream_));
+                    util::upload_small(dconst.get(), cs.data(), T * 8, stream_);
                     util::hip_check(moai_ckks_encode_masked(dev_, reinterpret_cast<const double *>(dconst.get()),
                                                             reinterpret_cast<const std::int32_t *>(terms[i].mask->dev->get()),
                                                             terms[i].mask->host.size(), T, dP.get(), L_, nullptr, terms[i].pscale, nullptr, stream_));
                     util::hip_check(moai_vector_dot(dev_, ptrs.data(), dP.get(), T, base, out->get(), size_, L_, stream_));
-                    must_sync = true;
                 }
                 base = out->get();
                 i = j;
-            }
-            if (must_sync)
-            {
-                util::hip_check(moai_stream_sync(stream_)); // the constants' host vectors
             }
             buf_ = out;
             lazy_.reset(); // the terms' blocks are released behind the kernel that read them (stream order)

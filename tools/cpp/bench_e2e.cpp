@@ -272,6 +272,11 @@ static int run(int argc, char **argv)
                    (unsigned long long)(fresh1.first - fresh0.first), fresh1.second - fresh0.second);
         }
         ops_head = census_json();
+        {
+            const auto rc = seal::util::RotationCache::instance().statistics();
+            printf("  [rotation cache during the head: %llu hits, %llu misses (key switches made)]\n", (unsigned long long)rc.first,
+                   (unsigned long long)rc.second);
+        }
         // the same head in the clear with MOAI's approximations (tests/cpp/test_moai_attention.cpp explains the model)
         auto approx_exp = [](double x) { return pow(1 + x * 0.0078125, 128); };
         auto goldschmidt = [&](double x) {

@@ -509,7 +509,10 @@ def keyswitch_region(m, args, torch, np, dev, stream, cores):
                 "achieved": round(work / (t * 1e-3) / 1e9, 1), "peak": FP64_BFLY_PER_S / 1e9, "unit": "G(butterfly+MAC)/s",
                 "frac": round(work / (t * 1e-3) / FP64_BFLY_PER_S, 4),
                 "hbm_algorithmic_gbs": round(alg_bytes / (t * 1e-3) / 1e9, 1),
-                "traffic": (pmc or {}).get("l%d" % Lk),
+                # HBM bytes of one batch call from the committed PMC passes (per ciphertext at batch 64, times this batch; the key's
+                # share is amortised differently at other batch sizes -- a few per cent); null where no PMC run exists
+                "traffic": ((pmc or {}).get("l%d" % Lk) or {}).get("hbm_bytes_per_ciphertext", 0) * B or None,
+                "traffic_source": ("profiles/r03_ks_traffic.json, collected at commit %s" % (pmc or {}).get("collected_at_commit")) if (pmc or {}).get("l%d" % Lk) else None,
             },
         }
         if cores:

@@ -886,6 +886,41 @@ namespace seal
         }
 
         // SEAL/evaluator.cpp:155-240 / :263-350
+        // a deferred rotation that is made alone goes through the call combiner, like an eager one
+        static void install_single_rotation_hook()
+        {
+            static const bool once = [] {
+                util::single_rotation_hook() = [](moai_ctx *d, const std::uint64_t *in, std::uint64_t *out, std::size_t L, std::uint32_t elt,
+                                                  const std::uint64_t *key, void *stream) {
+                    util::OpCombiner &comb = util::OpCombiner::instance();
+                    if (!comb.enabled())
+                    {
+                        util::hip_check(moai_apply_galois_to(d, in, out, L, elt, key, 1, stream));
+                        return;
+                    }
+                    const std::size_t words = 2 * L * moai_ctx_coeff_count(d);
+                    comb.submit(util::OpCombiner::Key(0, L, elt, key, d), { in, out }, [&](const std::vector<util::OpCombiner::Request> &reqs) {
+                        if (reqs.size() == 1)
+                        {
+                            util::hip_check(moai_apply_galois_to(d, reqs[0].in, reqs[0].out, L, elt, key, 1, stream));
+                            return;
+                        }
+                        util::DeviceArray tmp(reqs.size() * words, stream);
+                        for (std::size_t i = 0; i < reqs.size(); i++)
+                        {
+                            util::hip_check(moai_memcpy_d2d(tmp.get() + i * words, reqs[i].in, words * 8, stream));
+                        }
+                        util::hip_check(moai_apply_galois(d, tmp.get(), L, elt, key, reqs.size(), stream));
+                        for (std::size_t i = 0; i < reqs.size(); i++)
+                        {
+                            util::hip_check(moai_memcpy_d2d(reqs[i].out, tmp.get() + i * words, words * 8, stream));
+                        }
+                    });
+                };
+                return true;
+            }();
+            (void)once;
+        }
         static bool lazy_products()
         {
             static const bool on = [] {
@@ -1091,6 +1126,70 @@ namespace seal
                 throw std::invalid_argument("CKKS encrypted must be in NTT form");
             }
             const std::size_t L = src.coeff_modulus_size();
+            if (lazy_products() && src.batch() == 1 && src.size() == 2 && galois_keys.generation() != 0)
+            {
+                // not made now (util::RotState): recorded, and made when the result is read -- together with the other rotations of
+                // the same step this thread has asked for meanwhile.  Everything that can throw has been checked above.
+                const std::size_t index = GaloisKeys::get_index(galois_elt);
+                std::shared_ptr<util::DeviceArray> kb = galois_keys.key_block(index, L);
+                install_single_rotation_hook();
+                std::shared_ptr<util::RotState> state;
+                if (&dst == &src && dst.rot_ && !dst.lazy_ && !dst.buf_)
+                {
+                    // one more step of a chain (the non-adjacent form's next power of two, SEAL/evaluator.cpp:2709-2720)
+                    if (dst.rot_.use_count() > 1)
+                    {
+                        auto own = std::make_shared<util::RotState>();
+                        {
+                            std::lock_guard<std::mutex> g(dst.rot_->mu);
+                            own->src = dst.rot_->src;
+                            own->elts = dst.rot_->elts;
+                            own->keys = dst.rot_->keys;
+                            own->key_ids = dst.rot_->key_ids;
+                            own->L = dst.rot_->L;
+                            own->n = dst.rot_->n;
+                            own->dev = dst.rot_->dev;
+                            own->stream = dst.rot_->stream;
+                        }
+                        dst.rot_ = own;
+                        util::rot_register(own);
+                    }
+                    std::lock_guard<std::mutex> g(dst.rot_->mu);
+                    dst.rot_->elts.push_back(galois_elt);
+                    dst.rot_->keys.push_back(kb);
+                    dst.rot_->key_ids.emplace_back(galois_keys.generation(), index);
+                    return;
+                }
+                src.materialize();
+                state = std::make_shared<util::RotState>();
+                state->src = src.buf_;
+                state->elts.push_back(galois_elt);
+                state->keys.push_back(kb);
+                state->key_ids.emplace_back(galois_keys.generation(), index);
+                state->L = L;
+                state->n = src.n_;
+                state->dev = dev();
+                state->stream = st();
+                if (&dst != &src)
+                {
+                    dst.release();
+                    dst.parms_id_ = src.parms_id_;
+                    dst.is_ntt_form_ = src.is_ntt_form_;
+                    dst.size_ = src.size_;
+                    dst.batch_ = 1;
+                    dst.n_ = src.n_;
+                    dst.L_ = src.L_;
+                    dst.scale_ = src.scale_;
+                }
+                dst.stream_ = st();
+                dst.dev_ = dev();
+                dst.buf_.reset();
+                dst.lazy_.reset();
+                dst.rot_ = state;
+                dst.deferred_.v.store(true, std::memory_order_release);
+                util::rot_register(state);
+                return;
+            }
             const std::uint64_t *key = galois_keys.device_key(GaloisKeys::get_index(galois_elt), L);
             // a rotation of this very block by this element with these keys may have been computed already (util::RotationCache)
             util::RotationCache &cache = util::RotationCache::instance();

@@ -746,6 +746,151 @@ namespace seal
             std::vector<std::int32_t> host;
             std::shared_ptr<DeviceArray> dev; // int32 [slots]
         };
+
+        // A single-ciphertext rotation that has been asked for but not made: the chain of Galois elements still to apply to the
+        // block `src` (one element for a step with a key of its own, several for a step that goes through the non-adjacent form).
+        // MOAI's Q K^T loop asks for the rotation of 64 ciphertexts by the same step one call after the other and only then reads
+        // the first of them (Ct_ct_matrix_mul.hpp:24-32): when one pending rotation has to be made, every other pending rotation
+        // of the same thread with the same next element, level and key is made WITH it -- one batched key switch (0.12 ms per
+        // ciphertext at l = 15 instead of 0.22) -- and the rotation cache is consulted and fed per member.  Each ciphertext gets
+        // exactly the key switches it asked for; the batched kernels compute every member independently (same bits as single
+        // calls, tests/test_gpu_parity.py).
+        struct RotState
+        {
+            std::mutex mu;
+            std::shared_ptr<DeviceArray> src;
+            std::vector<std::uint32_t> elts;
+            std::vector<std::shared_ptr<DeviceArray>> keys; // the device block of each element's key as it serves level L
+            std::vector<std::pair<std::uint64_t, std::size_t>> key_ids; // (generation, index): the rotation cache's name for it
+            std::size_t L = 0, n = 0;
+            moai_ctx *dev = nullptr;
+            void *stream = nullptr;
+        };
+        // how a rotation that found no company in its own thread is issued: the evaluator routes it through the call combiner
+        // (moai_combiner.h), where concurrent callers of OTHER threads with the same element, level and key share a batched call
+        inline std::function<void(moai_ctx *, const std::uint64_t *, std::uint64_t *, std::size_t, std::uint32_t, const std::uint64_t *, void *)> &
+        single_rotation_hook()
+        {
+            static std::function<void(moai_ctx *, const std::uint64_t *, std::uint64_t *, std::size_t, std::uint32_t, const std::uint64_t *, void *)> h;
+            return h;
+        }
+        inline std::vector<std::weak_ptr<RotState>> &rot_registry()
+        {
+            static thread_local std::vector<std::weak_ptr<RotState>> r;
+            return r;
+        }
+        inline void rot_register(const std::shared_ptr<RotState> &st)
+        {
+            auto &r = rot_registry();
+            if (r.size() >= 512)
+            {
+                r.erase(std::remove_if(r.begin(), r.end(),
+                                       [](const std::weak_ptr<RotState> &w) {
+                                           auto p = w.lock();
+                                           return !p || p->elts.empty();
+                                       }),
+                        r.end());
+                if (r.size() >= 512)
+                {
+                    r.erase(r.begin(), r.begin() + 256);
+                }
+            }
+            r.push_back(st);
+        }
+        // applies every element of `me` (and, step by step, of the calling thread's other pending rotations that can share a
+        // batched call with it); returns the block that holds me's result
+        inline std::shared_ptr<DeviceArray> rot_resolve(const std::shared_ptr<RotState> &me)
+        {
+            std::unique_lock<std::mutex> mine(me->mu);
+            RotationCache &cache = RotationCache::instance();
+            while (!me->elts.empty())
+            {
+                const std::uint32_t e = me->elts.front();
+                const DeviceArray *key = me->keys.front().get();
+                // peers: pending rotations registered by this thread with the same next step
+                std::vector<std::shared_ptr<RotState>> group{ me };
+                std::vector<std::unique_lock<std::mutex>> held;
+                for (auto &w : rot_registry())
+                {
+                    auto p = w.lock();
+                    if (!p || p == me || group.size() >= 64)
+                    {
+                        continue;
+                    }
+                    std::unique_lock<std::mutex> lk(p->mu, std::try_to_lock);
+                    if (lk.owns_lock() && !p->elts.empty() && p->elts.front() == e && p->keys.front().get() == key && p->L == me->L && p->dev == me->dev &&
+                        p->n == me->n)
+                    {
+                        group.push_back(p);
+                        held.push_back(std::move(lk));
+                    }
+                }
+                const std::size_t words = 2 * me->L * me->n;
+                // what the cache already holds needs no work
+                std::vector<std::size_t> todo;
+                std::vector<RotationCache::Key> ckeys(group.size());
+                for (std::size_t i = 0; i < group.size(); i++)
+                {
+                    RotState &g = *group[i];
+                    ckeys[i] = RotationCache::Key(g.src.get(), e, g.key_ids.front().first, g.key_ids.front().second, g.L);
+                    std::shared_ptr<DeviceArray> hit = cache.enabled() ? cache.find(ckeys[i]) : nullptr;
+                    if (hit)
+                    {
+                        g.src = hit;
+                    }
+                    else
+                    {
+                        todo.push_back(i);
+                    }
+                }
+                if (todo.size() == 1)
+                {
+                    RotState &g = *group[todo[0]];
+                    auto out = std::make_shared<DeviceArray>(words, g.stream);
+                    if (single_rotation_hook())
+                    {
+                        single_rotation_hook()(g.dev, g.src->get(), out->get(), g.L, e, key->get(), g.stream);
+                    }
+                    else
+                    {
+                        hip_check(moai_apply_galois_to(g.dev, g.src->get(), out->get(), g.L, e, key->get(), 1, g.stream));
+                    }
+                    if (cache.enabled())
+                    {
+                        cache.insert(ckeys[todo[0]], g.src, out);
+                    }
+                    g.src = out;
+                }
+                else if (todo.size() > 1)
+                {
+                    const std::size_t m = todo.size();
+                    DeviceArray tmp(m * words, me->stream);
+                    for (std::size_t t = 0; t < m; t++)
+                    {
+                        hip_check(moai_memcpy_d2d(tmp.get() + t * words, group[todo[t]]->src->get(), words * 8, me->stream));
+                    }
+                    hip_check(moai_apply_galois(me->dev, tmp.get(), me->L, e, key->get(), m, me->stream));
+                    for (std::size_t t = 0; t < m; t++)
+                    {
+                        RotState &g = *group[todo[t]];
+                        auto out = std::make_shared<DeviceArray>(words, g.stream);
+                        hip_check(moai_memcpy_d2d(out->get(), tmp.get() + t * words, words * 8, me->stream));
+                        if (cache.enabled())
+                        {
+                            cache.insert(ckeys[todo[t]], g.src, out);
+                        }
+                        g.src = out;
+                    }
+                }
+                for (auto &g : group)
+                {
+                    g->elts.erase(g->elts.begin());
+                    g->keys.erase(g->keys.begin());
+                    g->key_ids.erase(g->key_ids.begin());
+                }
+            }
+            return me->src;
+        }
     } // namespace util
 
     // =================================================================================================
@@ -1357,7 +1502,8 @@ namespace seal
             dev_ = o.dev_;
             buf_ = o.words() ? o.buf_ : nullptr;
             lazy_ = o.lazy_;
-            deferred_.v.store(static_cast<bool>(lazy_), std::memory_order_release);
+            rot_ = o.rot_;
+            deferred_.v.store(lazy_ || rot_, std::memory_order_release);
             return *this;
         }
         void resize(const SEALContext &context, parms_id_type parms_id, std::size_t size)
@@ -1394,6 +1540,7 @@ namespace seal
         {
             buf_.reset();
             lazy_.reset();
+            rot_.reset();
             deferred_.v.store(false, std::memory_order_release);
             size_ = 0;
             batch_ = 1;
@@ -1542,7 +1689,30 @@ namespace seal
             {
                 return;
             }
+            // a pending rotation (util::RotState): made now, together with the thread's other pending rotations of the same step.
+            // Not under the lock below: a rotation made alone waits in the call combiner for callers of OTHER threads, who must be
+            // able to get here; the state has a lock of its own (a second reader of this object waits there and finds the result).
+            std::shared_ptr<util::RotState> pending;
+            {
+                std::lock_guard<std::mutex> g(lazy_mutex());
+                pending = rot_;
+            }
+            if (pending)
+            {
+                std::shared_ptr<util::DeviceArray> block = util::rot_resolve(pending);
+                std::lock_guard<std::mutex> g(lazy_mutex());
+                if (rot_ == pending)
+                {
+                    buf_ = block;
+                    rot_.reset();
+                    deferred_.v.store(static_cast<bool>(lazy_), std::memory_order_release);
+                }
+            }
             std::lock_guard<std::mutex> g(lazy_mutex());
+            if (rot_)
+            {
+                return; // replaced meanwhile by the owner (not a const use): the owner's business
+            }
             if (!lazy_)
             {
                 deferred_.v.store(false, std::memory_order_release);
@@ -1640,7 +1810,8 @@ namespace seal
         double scale_ = 1.0;
         mutable std::shared_ptr<util::DeviceArray> buf_;
         mutable std::shared_ptr<std::vector<LazyTerm>> lazy_;
-        mutable Flag deferred_; // lazy_ != nullptr
+        mutable std::shared_ptr<util::RotState> rot_; // a pending rotation of rot_->src (then buf_ is empty and lazy_ unset)
+        mutable Flag deferred_; // lazy_ or rot_ is set
         moai_ctx *dev_ = nullptr;
         void *stream_ = nullptr;
     };
@@ -1722,7 +1893,13 @@ namespace seal
         }
         // the key for a switch at L data primes: the same pointer unless the key was trimmed below L (limit_to_chain_index),
         // in which case the full key comes back from its host copy first
-        const std::uint64_t *device_key(std::size_t index, std::size_t L) const;
+        const std::uint64_t *device_key(std::size_t index, std::size_t L) const
+        {
+            auto b = key_block(index, L);
+            return b ? b->get() : nullptr;
+        }
+        // the same as an owner of the block (a deferred rotation keeps its key alive until it is made)
+        std::shared_ptr<util::DeviceArray> key_block(std::size_t index, std::size_t L) const;
 
         // ---- level-trimmed residency (not part of the reference API) ---------------------------------------------------
         // A key switch at l data primes reads the digits J < l and the rows {0 .. l-1, special prime} of a key
@@ -1892,7 +2069,7 @@ namespace seal
             res_->levels[i] = levels;
         }
     }
-    inline const std::uint64_t *KSwitchKeys::device_key(std::size_t index, std::size_t L) const
+    inline std::shared_ptr<util::DeviceArray> KSwitchKeys::key_block(std::size_t index, std::size_t L) const
     {
         if (index >= keys_.size() || !keys_[index])
         {
@@ -1900,16 +2077,16 @@ namespace seal
         }
         if (!res_)
         {
-            return keys_[index]->get();
+            return keys_[index];
         }
         std::lock_guard<std::mutex> g(res_->mu);
         if (index < res_->regrown.size() && res_->regrown[index])
         {
-            return res_->regrown[index]->get();
+            return res_->regrown[index];
         }
         if (index >= res_->levels.size() || res_->levels[index] == 0 || L <= res_->levels[index])
         {
-            return keys_[index]->get();
+            return keys_[index];
         }
         // a switch above the level the key was trimmed to: the full key comes back.  The trimmed block stays where it is
         // (callers on other threads may hold its address); it is dropped with the key object.
@@ -1923,7 +2100,7 @@ namespace seal
         util::hip_check(moai_memcpy_h2d(full->get(), res_->host[index]->data(), res_->host[index]->size() * 8, context.stream()));
         context.sync();
         res_->regrown[index] = full;
-        return full->get();
+        return full;
     }
     inline const std::uint64_t *KSwitchKeys::hoist_correction(const SEALContext &context, std::size_t index, std::uint32_t galois_elt,
                                                               std::size_t L) const

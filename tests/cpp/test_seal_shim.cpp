@@ -493,6 +493,7 @@ static void concurrent_callers()
         {
             util::RotationCache::instance().clear();
             evaluator.rotate_vector(a, 1, gk, out);
+            (void)out.block_id(); // read it: a rotation nobody reads is never made
         }
         context.sync();
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
@@ -875,15 +876,20 @@ static void shared_blocks_and_rotation_cache()
         const auto s0 = cache.statistics();
         Ciphertext r1, r2, r3;
         evaluator.rotate_vector(a, 7, gk, r1); // 7 = 8 - 1: two key switches, both misses
+        CHECK(r1.is_deferred());               // ... once somebody reads the result (rotations are deferred, util::RotState)
+        (void)r1.block_id();
         const auto s1 = cache.statistics();
         CHECK(s1.second - s0.second == 2 && s1.first == s0.first);
         evaluator.rotate_vector(a, 7, gk, r2); // the same chain from the same block: two hits, no device work
+        (void)r2.block_id();
         const auto s2 = cache.statistics();
         CHECK(s2.first - s1.first == 2 && s2.second == s1.second);
         CHECK(r2.block_id() == r1.block_id() && r1.download() == r2.download());
         Ciphertext a_copy = a;
         evaluator.rotate_vector_inplace(a_copy, 9, gk); // 9 = 8 + 1: shares the first step (-1? no: +1) of nothing above, but...
         evaluator.rotate_vector(a, 15, gk, r3);          // 15 = 16 - 1: its first step (-1) was computed for 7
+        (void)a_copy.block_id();
+        (void)r3.block_id();
         const auto s3 = cache.statistics();
         CHECK(s3.first - s2.first >= 1);
         // writing into a rotation's result must not reach the cached block
@@ -900,6 +906,29 @@ static void shared_blocks_and_rotation_cache()
         cache.clear();
         evaluator.rotate_vector_inplace(fresh9, 9, gk);
         CHECK(fresh7.download() == r1_bits && fresh15.download() == r3.download() && fresh9.download() == a_copy.download());
+        // several ciphertexts rotated by the same step and read afterwards (MOAI's Q K^T loop): made in one batched call
+        {
+            cache.clear();
+            vector<Ciphertext> many(5), single(5);
+            for (int i = 0; i < 5; i++)
+            {
+                vector<double> w(encoder.slot_count(), 0.01 * (i + 1));
+                Plaintext pw;
+                encoder.encode(w, pow(2.0, 40), pw);
+                encryptor.encrypt(pw, many[i]);
+                single[i] = many[i];
+            }
+            for (int i = 0; i < 5; i++)
+            {
+                evaluator.rotate_vector_inplace(single[i], 11, gk); // 11 = 8 + 2 + 1 (NAF: -1, -4, 16): one at a time
+                (void)single[i].block_id();
+            }
+            cache.clear();
+            for (int i = 0; i < 5; i++) evaluator.rotate_vector_inplace(many[i], 11, gk); // all pending ...
+            for (int i = 0; i < 5; i++) CHECK(many[i].is_deferred());
+            for (int i = 0; i < 5; i++) CHECK(many[i].download() == single[i].download()); // ... made together at the first read
+            cache.clear();
+        }
         // new keys in the same object: nothing computed with the old ones may come back
         evaluator.rotate_vector(a, 1, gk, r1);
         const vector<uint64_t> old_key_bits = r1.download();

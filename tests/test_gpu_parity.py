@@ -600,6 +600,53 @@ def test_config2_shape_properties(moai):
     assert (dx.to_numpy(x.shape) == x).all()
 
 
+def test_config2_full_batch_properties(moai):
+    """BASELINE configs[1] at its FULL size -- N = 2^16, 44 x 60-bit primes, 256 ciphertexts x 2 polynomials = 11.8 GB resident --
+    through size-independent properties, all checked on the device: the round trip INTT(NTT(x)) = x on every one of the 22 528
+    rows, linearity NTT(x + y) = NTT(x) + NTT(y) on every row of a second half-batch, and the oracle on the 44 rows of the last
+    ciphertext's second polynomial (the far end of the buffer).  Residues generated on the device like bench.py's."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs torch on the GPU box for device-side generation")
+    logn, L, B = 16, 44, 256
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, [60] * L)
+    ctx = moai.Context(logn, primes)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty((B, 2, L, n), dtype=torch.int64, device=dev)
+    for i, q in enumerate(primes):
+        x[:, :, i, :] = torch.randint(0, q, (B, 2, n), dtype=torch.int64, device=dev, generator=gen)
+    x[0, 0, :, :8] = 0
+    for i, q in enumerate(primes):
+        x[0, 1, i, :8] = q - 1
+    ref = x.clone()
+    ctx.ntt_forward(x.data_ptr(), B * 2, L, stream=st)
+    torch.cuda.synchronize()
+    assert not torch.equal(x, ref)
+    last = x[B - 1, 1].cpu().numpy().view(np.uint64)
+    want = O.Context(logn, primes).ntt(ref[B - 1, 1].cpu().numpy().view(np.uint64).reshape(1, L, n), L)[0]
+    assert (last == want).all()
+    # linearity on the first half against the second half, row by row: NTT(a) + NTT(b) == NTT(a + b)  (mod q, canonical)
+    H = B // 2
+    s = torch.empty((H, 2, L, n), dtype=torch.int64, device=dev)
+    ctx.add(ref[:H].contiguous().data_ptr(), ref[H:].contiguous().data_ptr(), s.data_ptr(), H * 2, L, stream=st)
+    ctx.ntt_forward(s.data_ptr(), H * 2, L, stream=st)
+    t = torch.empty_like(s)
+    ctx.add(x[:H].contiguous().data_ptr(), x[H:].contiguous().data_ptr(), t.data_ptr(), H * 2, L, stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(s, t)
+    del s, t
+    ctx.ntt_inverse(x.data_ptr(), B * 2, L, stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    del x, ref
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("logn", [12, 13, 15, 16])
 def test_forward_ntt_guard_every_second_stage(moai, logn):
     """59..61-bit primes take the integer butterflies with one guard per two stages (modarith.hip.h M_GUARD2, values up

@@ -829,16 +829,13 @@ namespace seal
                 // what the cache already holds needs no work
                 std::vector<std::size_t> todo;
                 std::vector<RotationCache::Key> ckeys(group.size());
+                std::vector<std::shared_ptr<DeviceArray>> next(group.size()); // committed together below: a failure half-way changes nothing
                 for (std::size_t i = 0; i < group.size(); i++)
                 {
                     RotState &g = *group[i];
                     ckeys[i] = RotationCache::Key(g.src.get(), e, g.key_ids.front().first, g.key_ids.front().second, g.L);
-                    std::shared_ptr<DeviceArray> hit = cache.enabled() ? cache.find(ckeys[i]) : nullptr;
-                    if (hit)
-                    {
-                        g.src = hit;
-                    }
-                    else
+                    next[i] = cache.enabled() ? cache.find(ckeys[i]) : nullptr;
+                    if (!next[i])
                     {
                         todo.push_back(i);
                     }
@@ -855,11 +852,7 @@ namespace seal
                     {
                         hip_check(moai_apply_galois_to(g.dev, g.src->get(), out->get(), g.L, e, key->get(), 1, g.stream));
                     }
-                    if (cache.enabled())
-                    {
-                        cache.insert(ckeys[todo[0]], g.src, out);
-                    }
-                    g.src = out;
+                    next[todo[0]] = out;
                 }
                 else if (todo.size() > 1)
                 {
@@ -875,18 +868,23 @@ namespace seal
                         RotState &g = *group[todo[t]];
                         auto out = std::make_shared<DeviceArray>(words, g.stream);
                         hip_check(moai_memcpy_d2d(out->get(), tmp.get() + t * words, words * 8, me->stream));
-                        if (cache.enabled())
-                        {
-                            cache.insert(ckeys[todo[t]], g.src, out);
-                        }
-                        g.src = out;
+                        next[todo[t]] = out;
                     }
                 }
-                for (auto &g : group)
+                for (std::size_t t : todo)
                 {
-                    g->elts.erase(g->elts.begin());
-                    g->keys.erase(g->keys.begin());
-                    g->key_ids.erase(g->key_ids.begin());
+                    if (cache.enabled())
+                    {
+                        cache.insert(ckeys[t], group[t]->src, next[t]);
+                    }
+                }
+                for (std::size_t i = 0; i < group.size(); i++)
+                {
+                    RotState &g = *group[i];
+                    g.src = next[i];
+                    g.elts.erase(g.elts.begin());
+                    g.keys.erase(g.keys.begin());
+                    g.key_ids.erase(g.key_ids.begin());
                 }
             }
             return me->src;

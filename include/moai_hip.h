@@ -140,6 +140,11 @@ int moai_scalar_dot(moai_ctx *ctx, const uint64_t *const *x, const uint64_t *sca
  * pointers as above; p: DEVICE [terms][L][N], the plaintexts back to back in NTT form (moai_ckks_encode_masked writes them so). */
 int moai_vector_dot(moai_ctx *ctx, const uint64_t *const *x, const uint64_t *p, size_t terms, const uint64_t *base, uint64_t *out,
                     size_t size, size_t L, void *stream);
+/* ... and for ciphertext operands: out[3][L][N] = base + sum_t multiply(x[t], y[t]) with size-2 operands in separate blocks
+ * (Evaluator::multiply's ckks_multiply, SEAL/evaluator.cpp:770-909, then add_inplace: the inner loops of MOAI's
+ * Ct_ct_matrix_mul.hpp:32-41 and :121-134).  x, y: HOST arrays of `terms` device pointers; base: device [3][L][N] or NULL. */
+int moai_ct_dot_ptrs(moai_ctx *ctx, const uint64_t *const *x, const uint64_t *const *y, size_t terms, const uint64_t *base, uint64_t *out,
+                     size_t L, void *stream);
 
 /* ---- ciphertext products -------------------------------------------------------------------------
  * Evaluator::ckks_multiply SEAL/evaluator.cpp:770-909, size 2 x size 2 -> size 3:

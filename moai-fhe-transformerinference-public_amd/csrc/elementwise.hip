@@ -237,6 +237,73 @@ __global__ __launch_bounds__(256) void vector_dot_kernel(VectorDotArgs g)
     }
 }
 
+// out[3][L][N] = base + sum_t multiply(x[t], y[t])  for size-2 ciphertexts that sit in separate blocks: the multiply + add_inplace chain
+// of MOAI's ct x ct products (Ct_ct_matrix_mul.hpp:32-41, 121-134) with the pairs' pointers in the kernel arguments
+struct CtDotPtrArgs
+{
+    const uint64_t *x[SCALAR_DOT_TERMS]; // each [2][L][N]
+    const uint64_t *y[SCALAR_DOT_TERMS];
+    const uint64_t *base;                // [3][L][N] or nullptr
+    uint64_t *out;                       // [3][L][N], may be `base`
+    const PrimeConst *pc;
+    uint32_t L, n2, terms;
+};
+
+__device__ __forceinline__ void mac128(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b);
+__global__ __launch_bounds__(256) void ct_dot_ptrs_kernel(CtDotPtrArgs g)
+{
+    const uint32_t prime = blockIdx.y;
+    const PrimeConst *pc = g.pc + prime;
+    const uint64_t q = pc->q, cr0 = pc->cr0, cr1 = pc->cr1;
+    const size_t rs = g.n2, p1 = (size_t)g.L * rs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        const size_t at = (size_t)prime * rs + i;
+        uint64_t lo[6], hi[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            lo[k] = hi[k] = 0;
+        }
+        if (g.base)
+        {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(g.base) + at;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+            {
+                const ulonglong2 v = b[(size_t)k * p1];
+                lo[2 * k] = v.x;
+                lo[2 * k + 1] = v.y;
+            }
+        }
+        // sixteen pairs: at most 32 products below 2^122 per sum on top of a base below 2^61 -- no overflow of 128 bits
+#pragma unroll 4
+        for (uint32_t t = 0; t < g.terms; ++t)
+        {
+            const ulonglong2 *xa = reinterpret_cast<const ulonglong2 *>(g.x[t]) + at;
+            const ulonglong2 *ya = reinterpret_cast<const ulonglong2 *>(g.y[t]) + at;
+            const ulonglong2 a0 = xa[0], a1 = xa[p1], b0 = ya[0], b1 = ya[p1];
+            mac128(lo[0], hi[0], a0.x, b0.x);
+            mac128(lo[1], hi[1], a0.y, b0.y);
+            mac128(lo[2], hi[2], a0.x, b1.x);
+            mac128(lo[2], hi[2], a1.x, b0.x);
+            mac128(lo[3], hi[3], a0.y, b1.y);
+            mac128(lo[3], hi[3], a1.y, b0.y);
+            mac128(lo[4], hi[4], a1.x, b1.x);
+            mac128(lo[5], hi[5], a1.y, b1.y);
+        }
+        ulonglong2 *o = reinterpret_cast<ulonglong2 *>(g.out) + at;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            ulonglong2 r;
+            r.x = barrett128(lo[2 * k], hi[2 * k], q, cr0, cr1);
+            r.y = barrett128(lo[2 * k + 1], hi[2 * k + 1], q, cr0, cr1);
+            o[(size_t)k * p1] = r;
+        }
+    }
+}
+
 struct CtMulArgs
 {
     const uint64_t *x; // [batch][2][L][N]
@@ -1083,6 +1150,59 @@ extern "C" int moai_scalar_dot(moai_ctx *c, const uint64_t *const *x, const uint
             g.s[w] = scalars[t0 * L + w];
         }
         hipLaunchKernelGGL(scalar_dot_kernel, row_grid(c, size * L), dim3(256), 0, (hipStream_t)stream, g);
+        MOAI_LAUNCH_CHECK();
+        t0 += cnt;
+    } while (t0 < terms);
+    return MOAI_OK;
+}
+
+extern "C" int moai_ct_dot_ptrs(moai_ctx *c, const uint64_t *const *x, const uint64_t *const *y, size_t terms, const uint64_t *base, uint64_t *out,
+                                size_t L, void *stream)
+{
+    MOAI_AUDIT(stream, base, out);
+    for (size_t t = 0; x && y && t < terms; ++t)
+    {
+        MOAI_AUDIT(stream, x[t], y[t]);
+    }
+    trace_op("ct_dot", L, terms);
+    int rc = check_rows(c, 3, L);
+    if (rc)
+    {
+        return rc;
+    }
+    if (L == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!out || (terms && (!x || !y)))
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    for (size_t t = 0; t < terms; ++t)
+    {
+        if (!x[t] || !y[t] || x[t] == out || y[t] == out)
+        {
+            return set_error(MOAI_EINVAL, "null operand, or an operand that is the output");
+        }
+    }
+    MOAI_CHECK_GRID_ROWS(L);
+    size_t t0 = 0;
+    do
+    {
+        const size_t cnt = std::min<size_t>(SCALAR_DOT_TERMS, terms - t0);
+        CtDotPtrArgs g;
+        for (size_t t = 0; t < (size_t)SCALAR_DOT_TERMS; ++t)
+        {
+            g.x[t] = t < cnt ? x[t0 + t] : nullptr;
+            g.y[t] = t < cnt ? y[t0 + t] : nullptr;
+        }
+        g.base = t0 == 0 ? base : out;
+        g.out = out;
+        g.pc = c->pc;
+        g.L = (uint32_t)L;
+        g.n2 = (uint32_t)(c->n >> 1);
+        g.terms = (uint32_t)cnt;
+        hipLaunchKernelGGL(ct_dot_ptrs_kernel, row_grid(c, L), dim3(256), 0, (hipStream_t)stream, g);
         MOAI_LAUNCH_CHECK();
         t0 += cnt;
     } while (t0 < terms);

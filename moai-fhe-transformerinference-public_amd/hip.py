@@ -78,6 +78,7 @@ SYMBOLS = {
     "moai_op_trace_dump": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "moai_scalar_dot": (C.c_int, [vp, C.POINTER(vp), u64p, sz, vp, vp, sz, sz, vp]),
     "moai_vector_dot": (C.c_int, [vp, C.POINTER(vp), vp, sz, vp, vp, sz, sz, vp]),
+    "moai_ct_dot_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), sz, vp, vp, sz, vp]),
     "moai_key_words": (sz, [vp, sz]),
     "moai_key_trim": (C.c_int, [vp, vp, sz, vp, vp]),
     "moai_key_forget": (C.c_int, [vp, vp]),
@@ -333,6 +334,13 @@ class Context:
         T = len(xs)
         arr = (vp * T)(*[_ptr(x) for x in xs])
         _check(lib().moai_vector_dot(self.h, arr, _ptr(plains), T, _ptr(base), _ptr(out), size, L, stream))
+
+    def ct_dot_ptrs(self, xs, ys, base, out, L, stream=None):
+        """out[3][L][N] = base + sum_t multiply(xs[t], ys[t]) for size-2 ciphertexts in separate buffers"""
+        T = len(xs)
+        ax = (vp * T)(*[_ptr(x) for x in xs])
+        ay = (vp * T)(*[_ptr(y) for y in ys])
+        _check(lib().moai_ct_dot_ptrs(self.h, ax, ay, T, _ptr(base), _ptr(out), L, stream))
 
     def key_trim(self, full_key, levels, stream=None):
         """the part of a key a switch at <= `levels` data primes reads, as a DeviceBuffer [levels][2][levels+1][N] whose layout the

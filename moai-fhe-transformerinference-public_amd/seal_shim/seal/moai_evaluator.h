@@ -150,6 +150,31 @@ namespace seal
                 throw std::invalid_argument("encrypted1 and encrypted2 pack different numbers of ciphertexts");
             }
             const std::size_t L = encrypted1.coeff_modulus_size(), B = encrypted1.batch();
+            if (size1 == 2 && size2 == 2 && B == 1 && &encrypted1 != &encrypted2 && lazy_products())
+            {
+                // not computed now: the product is recorded as (block, block) and summed with the products add_inplace brings
+                // (Ciphertext::LazyTerm::src2; MOAI's ct x ct loops, Ct_ct_matrix_mul.hpp:32-41, 121-134); a square is always eager
+                Ciphertext::LazyTerm term;
+                term.src = (encrypted1.materialize(), encrypted1.buf_);
+                term.src2 = (encrypted2.materialize(), encrypted2.buf_);
+                if (term.src != term.src2)
+                {
+                    out.release();
+                    out.stream_ = st();
+                    out.dev_ = dev();
+                    out.parms_id_ = encrypted1.parms_id_;
+                    out.is_ntt_form_ = true;
+                    out.size_ = 3;
+                    out.batch_ = 1;
+                    out.n_ = encrypted1.n_;
+                    out.L_ = encrypted1.L_;
+                    out.scale_ = new_scale;
+                    out.lazy_ = std::make_shared<std::vector<Ciphertext::LazyTerm>>();
+                    out.lazy_->push_back(std::move(term));
+                    out.deferred_.v.store(true, std::memory_order_release);
+                    return;
+                }
+            }
             out.resize_batch(context_, encrypted1.parms_id(), size1 + size2 - 1, B);
             if (size1 != 2 || size2 != 2)
             {
@@ -932,7 +957,7 @@ namespace seal
         void addsub(Ciphertext &e1, const Ciphertext &e2, bool sub) const
         {
             check_pair(e1, e2);
-            if (!sub && e2.is_deferred() && e1.batch() == 1 && e1.size() == 2 && e2.size() == 2)
+            if (!sub && e2.is_deferred() && e1.batch() == 1 && e1.size() == e2.size() && (e1.size() == 2 || e1.size() == 3))
             {
                 // the addend is a deferred sum of scalar products: its terms join this ciphertext's (Ciphertext::LazyTerm)
                 std::shared_ptr<std::vector<Ciphertext::LazyTerm>> theirs;

@@ -1673,8 +1673,9 @@ namespace seal
         {
             std::shared_ptr<util::DeviceArray> src;
             std::vector<std::uint64_t> scalars;         // [L]: a scalar-encoded plaintext's constant rows, or empty:
-            std::shared_ptr<const util::SlotMask> mask; // a masked-constant vector plaintext (Plaintext::mask_)
+            std::shared_ptr<const util::SlotMask> mask; // a masked-constant vector plaintext (Plaintext::mask_), or unset:
             double c = 0, pscale = 0;
+            std::shared_ptr<util::DeviceArray> src2;    // a second size-2 CIPHERTEXT: the term is multiply(src, src2), size 3
         };
         static std::mutex &lazy_mutex()
         {
@@ -1730,10 +1731,20 @@ namespace seal
             {
                 std::vector<const std::uint64_t *> ptrs;
                 std::size_t j = i;
-                if (!terms[i].mask)
+                if (terms[i].src2)
+                {
+                    std::vector<const std::uint64_t *> ptrs2;
+                    for (; j < terms.size() && terms[j].src2; j++)
+                    {
+                        ptrs.push_back(terms[j].src->get());
+                        ptrs2.push_back(terms[j].src2->get());
+                    }
+                    util::hip_check(moai_ct_dot_ptrs(dev_, ptrs.data(), ptrs2.data(), ptrs.size(), base, out->get(), L_, stream_));
+                }
+                else if (!terms[i].mask)
                 {
                     std::vector<std::uint64_t> sc;
-                    for (; j < terms.size() && !terms[j].mask; j++)
+                    for (; j < terms.size() && !terms[j].mask && !terms[j].src2; j++)
                     {
                         ptrs.push_back(terms[j].src->get());
                         sc.insert(sc.end(), terms[j].scalars.begin(), terms[j].scalars.end());
@@ -1744,7 +1755,7 @@ namespace seal
                 {
                     const std::size_t chunk = std::max<std::size_t>(16, (std::size_t(1) << 30) / (L_ * n_ * 8));
                     std::vector<double> cs;
-                    for (; j < terms.size() && j - i < chunk && terms[j].mask == terms[i].mask && terms[j].pscale == terms[i].pscale; j++)
+                    for (; j < terms.size() && j - i < chunk && !terms[j].src2 && terms[j].mask == terms[i].mask && terms[j].pscale == terms[i].pscale; j++)
                     {
                         ptrs.push_back(terms[j].src->get());
                         cs.push_back(terms[j].c);

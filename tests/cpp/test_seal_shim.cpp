@@ -1038,6 +1038,41 @@ static void deferred_scalar_products()
     evaluator.multiply_plain_inplace(t7, W[7]);
     CHECK(lone.is_deferred() && lone.download() == t7.download());
 
+    // ---- ciphertext x ciphertext: multiply + add_inplace chains (Ct_ct_matrix_mul.hpp:32-41) are deferred as well ----
+    {
+        const int pairs = 19;
+        Ciphertext acc;
+        evaluator.multiply(X[0], X[1], acc);
+        CHECK(acc.is_deferred() && acc.size() == 3);
+        for (int j = 1; j < pairs; j++)
+        {
+            Ciphertext temp;
+            evaluator.multiply(X[j], X[j + 1], temp);
+            evaluator.add_inplace(acc, temp);
+        }
+        CHECK(acc.is_deferred());
+        // the comparator: the library's eager entry points on the same blocks
+        const size_t L = X[0].coeff_modulus_size(), words3 = 3 * L * N;
+        util::DeviceArray sum(words3, context.stream()), prod(words3, context.stream());
+        for (int j = 0; j < pairs; j++)
+        {
+            const Ciphertext &a = X[j], &b = X[j + 1];
+            util::hip_check(moai_ct_multiply(context.device(), a.device_data(), b.device_data(), j == 0 ? sum.get() : prod.get(), L, 1, context.stream()));
+            if (j > 0)
+            {
+                util::hip_check(moai_add(context.device(), sum.get(), prod.get(), sum.get(), 3, L, context.stream()));
+            }
+        }
+        vector<uint64_t> want3(words3);
+        util::hip_check(moai_memcpy_d2h(want3.data(), sum.get(), words3 * 8, context.stream()));
+        context.sync();
+        CHECK(acc.download() == want3);
+        // a square is never deferred, and a product of a ciphertext with a copy of itself is a square
+        Ciphertext sq, same = X[2];
+        evaluator.multiply(X[2], same, sq);
+        CHECK(!sq.is_deferred());
+    }
+
     // ---- the same with MOAI's masked weights: every weight a VECTOR  w * mask  (Ct_pt_matrix_mul.hpp:124-146) ----
     vector<int> mask(encoder.slot_count(), 0);
     for (size_t i = 0; i < mask.size(); i += 3) mask[i] = 1;

@@ -1141,3 +1141,27 @@ def test_vector_dot_is_the_chain_of_dyadic_products_and_adds(moai, logn, bits, L
     dacc = up(moai, base)
     ctx.vector_dot(dxs, dp, dacc, dacc, 2, L)
     assert (dacc.to_numpy((2, L, n)) == np.asarray(octx.add(base, want, 2, L)).reshape(2, L, n)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn,bits,L,terms", [(12, [51, 46, 58], 2, 19), (11, [60, 61, 46, 46], 4, 33)])
+def test_ct_dot_ptrs_is_the_chain_of_multiply_and_add(moai, logn, bits, L, terms):
+    """moai_ct_dot_ptrs: out = base + sum_t multiply(x_t, y_t) over ciphertexts in separate buffers against the oracle's ckks_multiply +
+    add chain (Ct_ct_matrix_mul.hpp:32-41), bit for bit: pair counts off the sixteen per launch, 60/61-bit primes, a base, in place."""
+    n = 1 << logn
+    primes = O.coeff_modulus_create(n, bits)
+    octx, ctx = O.Context(logn, primes), moai.Context(logn, primes)
+    rng = np.random.default_rng(terms * 3 + L)
+    xs = [O.uniform_rns(rng, primes[:L], (2,), n) for _ in range(terms)]
+    ys = [O.uniform_rns(rng, primes[:L], (2,), n) for _ in range(terms)]
+    want = np.asarray(octx.multiply(xs[0], ys[0], L)).reshape(3, L, n)
+    for t in range(1, terms):
+        want = np.asarray(octx.add(want, np.asarray(octx.multiply(xs[t], ys[t], L)).reshape(3, L, n), 3, L)).reshape(3, L, n)
+    dxs, dys = [up(moai, x) for x in xs], [up(moai, y) for y in ys]
+    dout = moai.DeviceBuffer(3 * L * n)
+    ctx.ct_dot_ptrs(dxs, dys, None, dout, L)
+    assert (dout.to_numpy((3, L, n)) == want).all()
+    base = O.uniform_rns(rng, primes[:L], (3,), n)
+    dacc = up(moai, base)
+    ctx.ct_dot_ptrs(dxs, dys, dacc, dacc, L)
+    assert (dacc.to_numpy((3, L, n)) == np.asarray(octx.add(base, want, 3, L)).reshape(3, L, n)).all()

@@ -716,6 +716,9 @@ struct CtPtDotArgs
 // P polynomials per thread: a plaintext value is loaded once and multiplied into P ciphertext polynomials (a plaintext row is
 // shared by the whole batch -- with one polynomial per thread it was fetched n_poly times).  blockIdx.y = group * L + prime, the
 // group holds polynomials group * P .. group * P + P - 1 (the last group may be short).
+// The sums stay on the integer units also for primes below 2^51: the lazy 128-bit accumulation pays one Barrett step per 32 terms,
+// an exact FP64 product has to be reduced term by term (fp_mulmod_q, 7 operations at the 32-bit multiply rate).  Measured in
+// round 3 on the bootstrap's baby-step sums, pack 48: 3.42 ms per launch in doubles against 2.90 ms here -- not kept.
 template <int P, bool TWO>
 __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
 {

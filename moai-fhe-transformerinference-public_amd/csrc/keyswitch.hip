@@ -670,17 +670,13 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
     const uint32_t n2 = (uint32_t)(n >> 1);
 
     // 1. t = INTT(target)      (evaluator.cpp:2804-2812)
-    MOAI_CHECK_GRID_ROWS(batch * L);
-    hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, target, t, (uint32_t)L,
-                       (uint32_t)target_stride_rows, (uint32_t)target_off_rows, NO_ZERO, n2);
-    MOAI_LAUNCH_CHECK();
     RowMap rm;
     int rc = make_rowmap(c, L, nullptr, &rm);
     if (rc)
     {
         return rc;
     }
-    rc = ntt_launch(c, t, batch, L, rm, true, s);
+    rc = ntt_launch(c, t, batch, L, rm, true, s, target, target_stride_rows, target_off_rows);
     if (rc)
     {
         return rc;
@@ -1486,16 +1482,13 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
         uint64_t *pc0 = reinterpret_cast<uint64_t *>(base + 256 + sz_t + sz_tmp + sz_acc + sz_last + sz_u);
         const uint32_t n2 = (uint32_t)(n >> 1);
         // t = INTT(c1), UNPERMUTED: once for all rotations
-        MOAI_CHECK_GRID_ROWS(batch * L);
-        hipLaunchKernelGGL(copy_rows_kernel, rgrid(c, batch * L), dim3(256), 0, s, in, t, (uint32_t)L, (uint32_t)(2 * L), (uint32_t)L, NO_ZERO, n2);
-        MOAI_LAUNCH_CHECK();
         RowMap rm;
         rc = make_rowmap(c, L, nullptr, &rm);
         if (rc)
         {
             return rc;
         }
-        rc = ntt_launch(c, t, batch, L, rm, true, s);
+        rc = ntt_launch(c, t, batch, L, rm, true, s, in, 2 * L, L);
         if (rc)
         {
             return rc;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 {
                     if (MODE >= M_FPN)
                     {
-                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))], u2d(bq1), u2d(bq2));
+                        ct_bfly_fp1_sel(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))], u2d(bq1), u2d(bq2), MODE == M_FPR && !(u & 1));
                     }
                     else
                     {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                     uint32_t t_ = (hi3 << 5) | ((uint32_t)j << 2) | lo2;
                     if (MODE >= M_FPN)
                     {
-                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], twr[(u == 3) ? 0 : (u == 4) ? 1 + (j >> 2) : 3 + (j >> 1)], u2d(bq1), u2d(bq2));
+                        ct_bfly_fp1_sel(x[j], x[j + half], twr[(u == 3) ? 0 : (u == 4) ? 1 + (j >> 2) : 3 + (j >> 1)], u2d(bq1), u2d(bq2), MODE == M_FPR && !(u & 1));
                     }
                     else
                     {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                     uint32_t t_ = (r << 3) | (uint32_t)j;
                     if (MODE >= M_FPN)
                     {
-                        ct_bfly_fp1<MODE == M_FPR>(x[j], x[j + half], twr[(u == 6) ? 7 + (j >> 2) : 9 + (j >> 1)], u2d(bq1), u2d(bq2));
+                        ct_bfly_fp1_sel(x[j], x[j + half], twr[(u == 6) ? 7 + (j >> 2) : 9 + (j >> 1)], u2d(bq1), u2d(bq2), MODE == M_FPR && !(u & 1));
                     }
                     else
                     {
@@ -354,6 +354,9 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             }
         }
         } // !direct
+        // FP64 modes: when the sixteen running sums are folded back to |.| <= q/2.  Every product is below 0.88 q (fp_mulmod_q with
+        // a balanced digit), so M_FPR (2^53 / q > 4) may add three of them to a folded sum, M_FPN (q < 2^52 / 25) sixteen
+        const bool fold = MODE == M_FPR ? ((J - j0) % 3u == 2u) : (((J - j0) & 15u) == 15u);
         if (MODE >= M_FPN && PF != 0)
         {
             // the same products and sums as below, in the same order per accumulator: the same bits
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 sm[4 * c + 2] = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kpb[c].x), qd, qinv);
                 sm[4 * c + 3] = u2d(lo1[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(kpb[c].y), qd, qinv);
             }
-            if (MODE == M_FPR || ((J - j0) & 15u) == 15u) // wave-uniform: one branch around all sixteen reductions
+            if (fold) // wave-uniform: one branch around all sixteen reductions
             {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -412,9 +415,8 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 double s1 = u2d(lo0[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(ka.y), qd, qinv);
                 double s2 = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kb.x), qd, qinv);
                 double s3 = u2d(lo1[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(kb.y), qd, qinv);
-                if (MODE == M_FPR || ((J - j0) & 15u) == 15u)
+                if (fold)
                 {
-                    // M_FPR: 2^52 / q may be as small as 2; M_FPN: sixteen terms of at most 0.9 q on top of q/2
                     s0 = fp_red(s0, qd, qinv);
                     s1 = fp_red(s1, qd, qinv);
                     s2 = fp_red(s2, qd, qinv);
@@ -824,7 +826,10 @@ struct LoadExpandLast
     }
 };
 
-// the same expansion for the FP64 modes: the integer result is below 2 q_i < 2^52, so the conversion is exact
+// the same expansion for the FP64 modes: the integer result is below 2 q_i < 2^52, so the conversion is exact.
+// (Measured in round 3 and not kept: the expansion entirely in doubles -- v = hi 2^32 + lo, hi * (2^32 mod q_i) reduced with
+// fp_mulmod_q, minus q_last mod q_i when v + half wraps -- is 22 % SLOWER per launch than this integer Barrett step, 372 against
+// 304 us at pack 48: FP64 operations issue at the rate of the 32-bit multiplies they replace, and there are more of them.)
 struct LoadExpandLastFp
 {
     uint64_t ql, half, q, cr1, fix, qd, qinv;

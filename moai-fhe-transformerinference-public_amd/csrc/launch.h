@@ -16,8 +16,10 @@ int enter_device(const moai_ctx *c);
 // arithmetic mode (modarith.hip.h M_*) of the forward transform under a context prime
 int ntt_mode(const moai_ctx *c, uint32_t prime);
 int make_rowmap(const moai_ctx *c, size_t L, const uint32_t *prime_index, RowMap *out);
+// src (inverse only): polynomial p's row r is read from src row p * src_stride_rows + src_off_rows + r, the result lands in
+// `data` [n_poly][L][N] -- the inverse transform of a slice of a larger layout without copying the slice first
 int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse,
-               hipStream_t s);
+               hipStream_t s, const uint64_t *src = nullptr, size_t src_stride_rows = 0, size_t src_off_rows = 0);
 // returns the context workspace grown to at least `bytes` (grows only outside stream capture)
 int workspace(moai_ctx *c, size_t bytes, hipStream_t s, void **out);
 // headroom: allocate max(1.25 x bytes, 1.5 x the current size) when the arena has to grow

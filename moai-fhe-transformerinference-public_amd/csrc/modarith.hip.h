@@ -169,7 +169,11 @@ __device__ __forceinline__ void ct_bfly_fp(uint64_t &xb, uint64_t &yb, uint64_t 
 // The same butterfly with the twiddle given as w alone (8 bytes instead of 16): the quotient is estimated from
 // RN(y w) * RN(1/q) like fp_mulmod_q.  The estimate is off by up to 3 * 2^-53 |y|, so the product comes out with
 // |v| < 2q for |y| < 2^52: sixteen stages from q/2 stay below 33 q (M_FPN needs 33 q < 2^52, true for primes
-// below 2^46.9); M_FPR reduces BOTH operands first, which keeps |v| < 0.9 q.
+// below 2^46.9); M_FPR (q < 2^51, so 2^53 > 4q) reduces BOTH operands first, which keeps |v| < 0.88 q and the outputs below
+// 1.38 q.  One stage without the reductions may follow such a stage: with |u|, |y| <= 1.38 q the estimate is off by at most
+// 0.5 + 3 * 2^-53 * 1.38 q < 1.54, so |v| < 1.54 q, h - c q = r - l stays an integer below 2^52 (|l| <= 2^49) and the outputs stay
+// below 2.92 q < 2^53: exact.  The key switch's contiguous pass therefore reduces at every SECOND stage (its input, the
+// strided pass's output, is below 2q).
 template <bool RED>
 __device__ __forceinline__ void ct_bfly_fp1(uint64_t &xb, uint64_t &yb, double w, double q, double qinv)
 {
@@ -182,6 +186,18 @@ __device__ __forceinline__ void ct_bfly_fp1(uint64_t &xb, uint64_t &yb, double w
     double v = fp_mulmod_q(y, w, q, qinv);
     xb = d2u(u + v);
     yb = d2u(u - v);
+}
+// the same with the choice as an argument: a constant once the caller's stage loop is unrolled
+__device__ __forceinline__ void ct_bfly_fp1_sel(uint64_t &xb, uint64_t &yb, double w, double q, double qinv, const bool red)
+{
+    if (red)
+    {
+        ct_bfly_fp1<true>(xb, yb, w, q, qinv);
+    }
+    else
+    {
+        ct_bfly_fp1<false>(xb, yb, w, q, qinv);
+    }
 }
 
 // Cooley-Tukey butterfly of M_GUARD2.  The reference subtracts 2q from x when x >= 2q in every butterfly to keep

@@ -208,11 +208,20 @@ static int launch_coop(moai_ctx *c, const NttArgs &base, bool inverse, void *sta
 }
 
 // data [n_poly][L][N]; rows maps row -> prime.  Returns a MOAI_* code.
-int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse, hipStream_t s)
+int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMap &rows, bool inverse, hipStream_t s,
+               const uint64_t *src, size_t src_stride_rows, size_t src_off_rows)
 {
     if (n_poly == 0 || L == 0)
     {
         return MOAI_OK;
+    }
+    if (src && !inverse)
+    {
+        return set_error(MOAI_ELOGIC, "only the inverse transform reads from another buffer");
+    }
+    if (src && (src_stride_rows > 0xffffffffull || src_off_rows > 0xffffffffull || src_off_rows + L > src_stride_rows))
+    {
+        return set_error(MOAI_EINVAL, "source slice outside its layout");
     }
     if (n_poly * L * (c->n >> (c->logn >= 12 ? 12 : 0)) > 0x7fffffffull || n_poly > 0xffffffffull)
     {
@@ -233,7 +242,26 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     a.L = (uint32_t)L;
     a.n_poly = (uint32_t)n_poly;
     a.total_work = 0;
+    a.src = nullptr;
+    a.src_stride = a.src_off = 0;
     const int logn = c->logn;
+    static const long coop_on = env_long("MOAI_NTT_COOP", 0);
+    if (src)
+    {
+        if (naive_requested() || logn <= 11 || coop_on)
+        {
+            // the paths that transform in place: bring the slice over first
+            const size_t row_bytes = c->n * sizeof(uint64_t);
+            MOAI_HIP_CHECK(hipMemcpy2DAsync(data, L * row_bytes, src + src_off_rows * c->n, src_stride_rows * row_bytes, L * row_bytes, n_poly,
+                                            hipMemcpyDeviceToDevice, s));
+        }
+        else
+        {
+            a.src = src;
+            a.src_stride = (uint32_t)src_stride_rows;
+            a.src_off = (uint32_t)src_off_rows;
+        }
+    }
     if (naive_requested() && logn >= 1)
     {
         uint32_t bx = (uint32_t)(((c->n >> 1) + 255) / 256);
@@ -335,6 +363,10 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     for (size_t p0 = 0; p0 < n_poly; p0 += chunk)
     {
         a.data = data + p0 * L * c->n;
+        if (a.src)
+        {
+            a.src = src + p0 * src_stride_rows * c->n;
+        }
         a.n_poly = (uint32_t)(n_poly - p0 < chunk ? n_poly - p0 : chunk);
         switch (logn)
         {

@@ -83,6 +83,11 @@ struct NttArgs
     uint32_t Lsel;
     uint32_t n_poly;
     uint32_t total_work;       // grid size
+    // inverse transform only: when set, the first pass reads polynomial p's row r from src row p * src_stride + src_off + r
+    // instead of from `data` (the transform of a slice of a larger layout, written into `data`, without a copy first)
+    const uint64_t *src;
+    uint32_t src_stride;
+    uint32_t src_off;
 };
 
 // (q, q2) arguments of a tile function under MODE: the integer pair, or the bit patterns of (double q, 1/q)
@@ -198,6 +203,12 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
         x[j] = op(irow[((e >> GB) << 8) + (e & (G - 1))]);
     }
     // phase A: top four bits of t live in the register index
+#ifdef MOAI_DIAG_NOCOMPUTE
+    const int diag_stages = (q == 0x7ff8dead0000beefull) ? 4 : 0; // diagnostic build: loads, exchange and stores only
+#define MOAI_DIAG_STAGE_OK(u) && ((u) < diag_stages)
+#else
+#define MOAI_DIAG_STAGE_OK(u)
+#endif
 #pragma unroll
     for (int u = 0; u < 4; ++u)
     {
@@ -205,7 +216,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
 #pragma unroll
         for (int j = 0; j < 16; ++j)
         {
-            if (!(j & half))
+            if (!(j & half) MOAI_DIAG_STAGE_OK(u))
             {
                 Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
                 ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - u);
@@ -250,7 +261,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
 #pragma unroll
             for (int j = 0; j < 16; ++j)
             {
-                if (!(j & half))
+                if (!(j & half) MOAI_DIAG_STAGE_OK(s - 4))
                 {
                     if (PRE)
                     {
@@ -269,6 +280,9 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
         for (int j = 0; j < 16; ++j)
         {
             uint32_t t_ = (th << 4) | (uint32_t)j;
+#ifdef MOAI_DIAG_NOSTORE
+            if (x[j] == 0x7ff8dead0000beefull) // diagnostic build: the arithmetic stays, the stores (practically) never happen
+#endif
             row[(t_ << 8) + g] = x[j];
         }
     }
@@ -472,13 +486,13 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 // =====================================================================================================
 // LZ: the M_LAZY8 butterflies (modarith.hip.h), with (q, q2) = (2^64 - q, 2^64 - 4q); values below 4q instead of 2q
 template <int LOGN, bool LZ = false>
-__device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
+__device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
-                                                const Tw *__restrict__ twb)
+                                                const Tw *__restrict__ twb, const uint64_t *srcp = nullptr)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
-    uint64_t *__restrict__ base = rowp + ((size_t)tile << 12);
+    uint64_t *base = rowp + ((size_t)tile << 12);
     const uint32_t b = tid >> 4;
     const uint32_t tl = tid & 15u;
     const uint32_t blk = (tile << 4) + b;
@@ -493,7 +507,8 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *__restrict__ rowp, uin
     {
         tb[i] = twbt[((uint32_t)i << 8) + tid];
     }
-    const ulonglong2 *__restrict__ in2 = reinterpret_cast<const ulonglong2 *>(base);
+    // the row read may be another buffer's (NttArgs::src) or the one written: the tile is whole in LDS before any of it is stored
+    const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(srcp ? srcp + ((size_t)tile << 12) : base);
     // every wave stages the 64 rows its own lanes transform (8 KiB, contiguous): the exchanges of this pass are wave-local
     const uint32_t wbase = (tid >> 6) << 9, lane = tid & 63u;
 #pragma unroll
@@ -575,8 +590,9 @@ __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
     const uint32_t r = __builtin_amdgcn_readfirstlane(a.sel.idx[rest / TPR]);
     const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[rest / TPR]);
     const PrimeConst &pc = a.pc[prime];
+    const uint64_t *srcp = a.src ? a.src + (((size_t)pol * a.src_stride + a.src_off + r) << LOGN) : nullptr;
     inv_contig_tile<LOGN, LZ>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN), LZ ? pc.nq : pc.q,
-                              LZ ? pc.n4q : pc.q2, lds2, threadIdx.x, a.twb + (size_t)prime * ((size_t)TPR * 15 * 256));
+                              LZ ? pc.n4q : pc.q2, lds2, threadIdx.x, a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), srcp);
 }
 
 // =====================================================================================================

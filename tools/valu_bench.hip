@@ -176,6 +176,39 @@ __global__ __launch_bounds__(256) void rmwk(ulonglong2 *__restrict__ a, size_t n
     }
 }
 
+
+// store-only kernels in the access shape of the strided NTT pass (a workgroup owns G columns of a 2^16-coefficient row and stores
+// 256 segments of G * 8 bytes, 2 KiB apart) against the same bytes stored contiguously.  ORDER 0: consecutive workgroups take
+// consecutive tiles of one row; 1: the same tile of consecutive rows (the production order: the twiddle slice is shared).
+template <int GB, int ORDER>
+__global__ __launch_bounds__(256) void wpat(uint64_t *__restrict__ out, uint32_t rows)
+{
+    constexpr uint32_t G = 1u << GB;            // columns per workgroup
+    constexpr uint32_t TILES = 256u / G;        // workgroups per row
+    constexpr uint32_t PER = (256u * G) / 256u; // stores per thread
+    const uint32_t w = blockIdx.x;
+    const uint32_t row = ORDER ? w % rows : w / TILES;
+    const uint32_t tile = ORDER ? w / rows : w % TILES;
+    uint64_t *__restrict__ r = out + ((size_t)row << 16) + tile * G;
+    const uint32_t g = threadIdx.x & (G - 1), th = threadIdx.x >> GB;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j)
+    {
+        const uint32_t t_ = th * PER + j;
+        r[(t_ << 8) + g] = (uint64_t)t_ * 0x9e3779b97f4a7c15ull + g;
+    }
+}
+__global__ __launch_bounds__(256) void wlin(ulonglong2 *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    {
+        ulonglong2 v;
+        v.x = i;
+        v.y = ~i;
+        out[i] = v;
+    }
+}
+
 template <int OP>
 int run(const char *name, double ops_per_iter, int cus, uint32_t *d)
 {
@@ -278,6 +311,42 @@ int main()
                 if (ms < best) best = ms;
             }
             printf("%-48s 4 GiB: %.3f ms -> %.2f TB/s (read+write)\n", names[variant], best, 2.0 * bytes / (best * 1e-3) * 1e-12);
+        }
+    }
+    {
+        const uint32_t rows = 96 * 30; // one mode group of a pack of 48 at l = 30
+        const size_t bytes = (size_t)rows << 19;
+        uint64_t *o;
+        CHK(hipMalloc(&o, bytes));
+        CHK(hipMemset(o, 0, bytes));
+        hipEvent_t e0, e1;
+        CHK(hipEventCreate(&e0));
+        CHK(hipEventCreate(&e1));
+        const char *names[] = { "store only, contiguous",
+                                "store only, 128 B segments 2 KiB apart, tiles of a row together",
+                                "store only, 128 B segments 2 KiB apart, one tile of many rows together",
+                                "store only, 256 B segments 2 KiB apart, tiles of a row together",
+                                "store only, 256 B segments 2 KiB apart, one tile of many rows together",
+                                "store only, 512 B segments 2 KiB apart, one tile of many rows together" };
+        for (int variant = 0; variant < 6; ++variant)
+        {
+            float best = 1e9;
+            for (int rep = 0; rep < 4; ++rep)
+            {
+                CHK(hipEventRecord(e0, 0));
+                if (variant == 0) hipLaunchKernelGGL(wlin, dim3(256 * 32), dim3(256), 0, 0, (ulonglong2 *)o, bytes / 16);
+                if (variant == 1) hipLaunchKernelGGL((wpat<4, 0>), dim3(rows * 16), dim3(256), 0, 0, o, rows);
+                if (variant == 2) hipLaunchKernelGGL((wpat<4, 1>), dim3(rows * 16), dim3(256), 0, 0, o, rows);
+                if (variant == 3) hipLaunchKernelGGL((wpat<5, 0>), dim3(rows * 8), dim3(256), 0, 0, o, rows);
+                if (variant == 4) hipLaunchKernelGGL((wpat<5, 1>), dim3(rows * 8), dim3(256), 0, 0, o, rows);
+                if (variant == 5) hipLaunchKernelGGL((wpat<6, 1>), dim3(rows * 4), dim3(256), 0, 0, o, rows);
+                CHK(hipEventRecord(e1, 0));
+                CHK(hipEventSynchronize(e1));
+                float ms;
+                CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            printf("%-72s %.2f GiB: %.3f ms -> %.2f TB/s (write)\n", names[variant], bytes / 1073741824.0, best, bytes / (best * 1e-3) * 1e-12);
         }
     }
     return 0;

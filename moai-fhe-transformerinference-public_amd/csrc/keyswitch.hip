@@ -571,7 +571,14 @@ static int ks_fused_group_mode(moai_ctx *c, const uint64_t *t, uint64_t *tmp, co
     p1.G = (uint32_t)G;
     p1.total_work = (uint32_t)(batch * G * L * TPR);
     p1.tw1 = c->fwd_twf1;
-    if (MODE == M_FPN && tuning("MOAI_KS_P1_PRE", 0))
+    // N = 2^16, FP64 modes, enough work to fill the chip that way: eight tiles per workgroup, software-pipelined
+    // (fwd_strided_tiles; MOAI_KS_P1_ITEMS=1: one tile per workgroup)
+    constexpr int P1_ITEMS = (LOGN == 16 && MODE >= M_FPN) ? 8 : 1;
+    if (P1_ITEMS > 1 && p1.total_work >= 8u * 2048u && tuning("MOAI_KS_P1_ITEMS", 8) > 1)
+    {
+        hipLaunchKernelGGL((ks_fwd_strided<LOGN, MODE, false, P1_ITEMS>), dim3(p1.total_work / P1_ITEMS), dim3(256), 0, s, p1);
+    }
+    else if (MODE == M_FPN && tuning("MOAI_KS_P1_PRE", 0))
     {
         hipLaunchKernelGGL((ks_fwd_strided<LOGN, MODE, MODE == M_FPN>), dim3(p1.total_work), dim3(256), 0, s, p1);
     }

@@ -39,20 +39,25 @@ struct KsP1Args
 //   M_NOGUARD  prime below 2^64/36 and 36 q^2 L < 2^128: no guards, and the unreduced digit (< 33q) goes
 //              straight into the 128-bit MAC
 //   M_FPN/FPR  prime below 2^51: FP64 butterflies (tw = the FP64 table), canonical integer into the MAC
-template <int LOGN, int MODE, bool PRE = false>
+// ITEMS > 1 (FP64 modes): a workgroup takes ITEMS consecutive tiles of its row, software-pipelined (fwd_strided_tiles); the grid
+// is total_work / ITEMS
+template <int LOGN, int MODE, bool PRE = false, int ITEMS = 1>
 __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
-    __shared__ uint64_t lds[4096];
-    uint32_t w = xcd_remap(blockIdx.x, a.total_work);
-    const uint32_t tile = w % TPR;
-    w /= TPR;
+    static_assert(ITEMS >= 1 && TPR % ITEMS == 0, "a workgroup's tiles belong to one row");
+    __shared__ uint64_t lds[4096 + (ITEMS > 1 ? 512 : 0)]; // the exchange buffer; pipelined: + phase B's twiddles
+    uint32_t w = xcd_remap(blockIdx.x, a.total_work / ITEMS);
+    const uint32_t tile = (w % (TPR / ITEMS)) * ITEMS;
+    w /= TPR / ITEMS;
     const uint32_t g = w % a.G;
     w /= a.G;
     const uint32_t J = w % a.L;
     const uint32_t b = w / a.L;
-    const uint32_t prime = a.grp.prime[g];
-    if (a.grp.slot[g] == J)
+    // 16-bit kernarg entries arrive through a vector load: pin them back to scalars, or the twiddle pointer lives in VGPRs and
+    // the uniform twiddles of phase A come through vector loads (whose waits would also cover the prefetch of the next tile)
+    const uint32_t prime = __builtin_amdgcn_readfirstlane(a.grp.prime[g]);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane(a.grp.slot[g]) == J)
     {
         // output modulus = the digit's own prime: the transform of the reduced digit is the target's NTT-form row
         // itself (the reference copies it, SEAL/evaluator.cpp:2836-2839); ks_contig_mac8 reads it from there
@@ -72,16 +77,30 @@ __global__ __launch_bounds__(256, 4) void ks_fwd_strided(KsP1Args a)
             op.cr1 = pc->cr1;
             op.qd = pc->qd;
             op.qinv = pc->qinv;
-            fwd_strided_tile<LOGN, LoadBarrettFp, MODE, PRE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op,
-                                                             PRE ? a.tw1 + ((size_t)prime << LOGN) : nullptr);
+            if constexpr (ITEMS > 1)
+            {
+                fwd_strided_tiles<LOGN, LoadBarrettFp, MODE, ITEMS>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+            }
+            else
+            {
+                fwd_strided_tile<LOGN, LoadBarrettFp, MODE, PRE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op,
+                                                                 PRE ? a.tw1 + ((size_t)prime << LOGN) : nullptr);
+            }
         }
         else
         {
             LoadFp52 op;
             op.qd = pc->qd;
             op.qinv = pc->qinv;
-            fwd_strided_tile<LOGN, LoadFp52, MODE, PRE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op,
-                                                        PRE ? a.tw1 + ((size_t)prime << LOGN) : nullptr);
+            if constexpr (ITEMS > 1)
+            {
+                fwd_strided_tiles<LOGN, LoadFp52, MODE, ITEMS>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op);
+            }
+            else
+            {
+                fwd_strided_tile<LOGN, LoadFp52, MODE, PRE>(in, out, tile, a.tw + ((size_t)prime << LOGN), pc->qd, pc->qinv, lds, threadIdx.x, op,
+                                                            PRE ? a.tw1 + ((size_t)prime << LOGN) : nullptr);
+            }
         }
     }
     // digit J is canonical under prime J: it needs reducing only when that prime is the larger one
@@ -915,6 +934,8 @@ struct ModDownArgs
     Tw scal[MOAI_MAX_RNS];
 };
 
+// (one tile per workgroup: the software-pipelined form of the key switch's strided pass, fwd_strided_tiles, measured the same here --
+// 313 against 308 us per launch at pack 48 -- this pass is bound by its load operation's arithmetic)
 template <int LOGN, int MODE>
 __global__ __launch_bounds__(256, 4) void moddown_strided(ModDownArgs a)
 {

@@ -35,6 +35,10 @@ static void launch_fwd_mode(const moai_ctx *c, NttArgs a, hipStream_t s)
         a.tw = c->fwd_twf;
         a.twb = c->fwd_twfb;
     }
+    // (the software-pipelined strided pass of the key switch, fwd_strided_tiles, does not pay here: measured in round 3 on 256 x 2
+    // polynomials, 11.25 against 11.37 ms with the bench's 60-bit primes and 7.77 against 7.40 ms -- slower -- with MOAI's FP64
+    // rows.  An in-place transform reads as much as it writes and has no cached operand; five resident workgroups of one tile
+    // each keep more of that traffic in flight than four pipelined ones.)
     hipLaunchKernelGGL((ntt_fwd_strided<LOGN, MODE>), dim3(a.total_work), dim3(256), 0, s, a);
     hipLaunchKernelGGL((ntt_fwd_contig<LOGN, MODE>), dim3(a.total_work), dim3(256), 0, s, a);
 }

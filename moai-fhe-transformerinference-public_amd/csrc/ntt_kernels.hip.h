@@ -183,25 +183,39 @@ __device__ __forceinline__ void ct_bfly_stage(uint64_t &x, uint64_t &y, uint64_t
 // butterflies that use them (ten exposed round trips to L2 per tile in the compiled loop); the butterflies then take their
 // quotient estimate from RN(y w) RN(1/q) like the contiguous key-switch pass (ct_bfly_fp1: growth below 2q per stage instead of
 // 0.75q; 46-bit primes still end all sixteen stages below 28q < 2^52).  Same residues.
-template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD, bool PRE = false>
-__device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
-                                                 const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
-                                                 const uint32_t tid, LoadOp op = LoadOp(), const double *__restrict__ tw1 = nullptr)
+// the 16 values a thread takes from its tile of the input row (tile base = row + tile * G), not yet converted
+template <int LOGN>
+__device__ __forceinline__ void strided_load_raw(const uint64_t *__restrict__ irow, const uint32_t tid, uint64_t (&raw)[16])
 {
-    constexpr int R1 = LOGN - 8;
-    constexpr int RB = R1 - 4;
-    constexpr int GB = 12 - R1;
+    constexpr int GB = 12 - (LOGN - 8);
     constexpr uint32_t G = 1u << GB;
-    uint64_t *__restrict__ row = rowp + tile * G;
-    const uint64_t *__restrict__ irow = inp + tile * G;
-
-    uint64_t x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {
         uint32_t e = (uint32_t)j * 256u + tid;
-        x[j] = op(irow[((e >> GB) << 8) + (e & (G - 1))]);
+        raw[j] = irow[((e >> GB) << 8) + (e & (G - 1))];
     }
+}
+
+// everything after the load: the butterflies of both phases, the exchange and the stores of one tile (row = tile base of the
+// output row).  SYNC_FIRST: the workgroup has used `lds` for an earlier tile -- wait until everybody has read it.  The barriers
+// wait for LDS traffic only (lds_barrier), so global loads and stores of neighbouring tiles stay in flight across them.
+// LDSTW: phase B takes its twiddles (entries 16..255 of the table) from the workgroup's copy in LDS, `ldstw`
+template <int LOGN, int MODE, bool PRE, bool SYNC_FIRST, bool LDSTW = false>
+__device__ __forceinline__ void strided_core(uint64_t (&x)[16], uint64_t *__restrict__ row, const Tw *__restrict__ tw, uint64_t q,
+                                             uint64_t q2, uint64_t *lds, const uint32_t tid, const double *__restrict__ tw1,
+                                             const Tw *ldstw = nullptr)
+{
+    // phase A's fifteen twiddles (entries 1..15 of the table) are the same for every thread: read through the constant address
+    // space, so that they stay SCALAR loads also inside a loop over tiles -- behind the stores of an earlier iteration the compiler
+    // turns a uniform global load into a vector load (it cannot see that no kernel ever writes the tables), and the wait for a
+    // vector load also waits for the prefetch of the next tile issued before it
+    typedef const Tw __attribute__((address_space(4))) *TwConst;
+    const TwConst twa = (TwConst)(uintptr_t)tw;
+    constexpr int R1 = LOGN - 8;
+    constexpr int RB = R1 - 4;
+    constexpr int GB = 12 - R1;
+    constexpr uint32_t G = 1u << GB;
     // phase A: top four bits of t live in the register index
 #ifdef MOAI_DIAG_NOCOMPUTE
     const int diag_stages = (q == 0x7ff8dead0000beefull) ? 4 : 0; // diagnostic build: loads, exchange and stores only
@@ -218,8 +232,8 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
         {
             if (!(j & half) MOAI_DIAG_STAGE_OK(u))
             {
-                Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
-                ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - u);
+                const uint32_t ti = (1u << u) + (uint32_t)(j >> (4 - u));
+                ct_bfly_stage<MODE>(x[j], x[j + half], twa[ti].w, twa[ti].wq, q, q2, LOGN - 1 - u);
             }
         }
     }
@@ -240,12 +254,16 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
                 }
             }
         }
+        if (SYNC_FIRST)
+        {
+            lds_barrier();
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j)
         {
             lds[phys_strided<GB>((uint32_t)j * 256u + tid)] = x[j];
         }
-        __syncthreads();
+        lds_barrier();
         const uint32_t g = tid & (G - 1);
         const uint32_t th = tid >> GB;
 #pragma unroll
@@ -270,7 +288,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
                     else
                     {
                         uint32_t t_ = (th << 4) | (uint32_t)j;
-                        Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
+                        Tw t = LDSTW ? ldstw[(1u << s) + (t_ >> (R1 - s))] : tw[(1u << s) + (t_ >> (R1 - s))];
                         ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, LOGN - 1 - s);
                     }
                 }
@@ -283,7 +301,7 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
 #ifdef MOAI_DIAG_NOSTORE
             if (x[j] == 0x7ff8dead0000beefull) // diagnostic build: the arithmetic stays, the stores (practically) never happen
 #endif
-            row[(t_ << 8) + g] = x[j];
+            row[(t_ << 8) + g] = x[j]; // (non-temporal stores measured the same: 2080 against 2092 us in the key switch's pass)
         }
     }
     else
@@ -293,6 +311,73 @@ __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ in
         {
             uint32_t e = (uint32_t)j * 256u + tid;
             row[((e >> GB) << 8) + (e & (G - 1))] = x[j];
+        }
+    }
+}
+
+template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD, bool PRE = false>
+__device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
+                                                 const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
+                                                 const uint32_t tid, LoadOp op = LoadOp(), const double *__restrict__ tw1 = nullptr)
+{
+    constexpr uint32_t G = 1u << (12 - (LOGN - 8));
+    uint64_t x[16];
+    strided_load_raw<LOGN>(inp + tile * G, tid, x);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+    {
+        x[j] = op(x[j]);
+    }
+    strided_core<LOGN, MODE, PRE, false>(x, rowp + tile * G, tw, q, q2, lds, tid, tw1);
+}
+
+// ITEMS consecutive tiles of one row by one workgroup, software-pipelined: the loads of tile i + 1 are issued before the
+// butterflies of tile i, and the stores of tile i drain under the butterflies of tile i + 1.  A workgroup that loads, computes and
+// stores ONE tile keeps the memory system busy only through its neighbours on the CU, and 32 KiB of LDS plus ~96 VGPRs allow four
+// or five of them: measured on the key switch's strided pass (round 3, tools/diag), 2.37 ms per launch against 1.96 ms for its
+// memory traffic alone and 1.62 ms for its arithmetic alone -- the two did not overlap.
+template <int LOGN, class LoadOp, int MODE, int ITEMS>
+__device__ __forceinline__ void fwd_strided_tiles(const uint64_t *inp, uint64_t *rowp, uint32_t tile0,
+                                                  const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds, const uint32_t tid,
+                                                  LoadOp op)
+{
+    constexpr uint32_t G = 1u << (12 - (LOGN - 8));
+    static_assert(LOGN == 16, "the LDS copy holds the 256 entries phase B of N = 2^16 indexes");
+    uint64_t raw[16], x[16];
+    strided_load_raw<LOGN>(inp + tile0 * G, tid, raw);
+    // phase B's twiddles into LDS (`lds` + 4096 words: 256 entries of 16 bytes, one per thread; entries 16..255 are used).
+    // Fetched from memory inside the loop, every wait for one of them would also wait for the stores of the previous tile
+    // and for the prefetch of the next one: vector memory operations complete in order.
+    Tw *ldstw = reinterpret_cast<Tw *>(lds + 4096);
+    ldstw[tid] = tw[tid];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+    {
+        x[j] = op(raw[j]);
+    }
+    // one loop body (not unrolled: four copies of it would not fit the instruction cache).  The first tile's values are converted
+    // before the loop, so the body starts from arithmetic results and not from pending loads: entered that way, its first wait
+    // would also cover the loads it has just issued.
+#pragma unroll 1
+    for (uint32_t it = 0; it < (uint32_t)ITEMS; ++it)
+    {
+        // opaque copy of the thread index: the per-thread addresses (16 loads, 16 stores, 32 LDS slots, the twiddles) are
+        // recomputed in every iteration instead of hoisted out of the loop into registers the prefetch needs
+        uint32_t t = tid;
+        asm volatile("" : "+v"(t));
+        const bool more = it + 1u < (uint32_t)ITEMS;
+        if (more)
+        {
+            strided_load_raw<LOGN>(inp + (tile0 + it + 1u) * G, t, raw);
+        }
+        strided_core<LOGN, MODE, false, true, true>(x, rowp + (tile0 + it) * G, tw, q, q2, lds, t, nullptr, ldstw);
+        if (more)
+        {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+            {
+                x[j] = op(raw[j]);
+            }
         }
     }
 }

@@ -174,6 +174,11 @@ __device__ __forceinline__ uint32_t phys8_b(uint32_t e)
 // straightforward loop (the periodic reduction's branch keeps it from moving them): four exposed L2 round trips per digit.
 // 1: all eight at the head of the MAC, one wait.  2: all eight at the head of the iteration, next to the digit's own loads,
 // so that they are in flight during the whole transform (32 more registers live across it).
+// (Measured in round 3 and not kept: the digit's VALUES prefetched one digit ahead without registers -- each wave copying the next
+// digit's 4 KiB into its own part of exchange buffer A with global_load_lds_dwordx4 as soon as it has read that buffer back, the
+// twiddles of stages 0..2 in LDS, no global load at the head of an iteration: bit-identical, 0.496 against 0.502 ms per key switch
+// at l = 35 and 0.120 against 0.118 at l = 15 -- noise.  The wait for the key residues at the head of the MAC also waits for the
+// copy issued before them (vector memory operations complete in order), and the kernel's idle fifth is not this round trip.)
 template <int LOGN, int MODE, int PF = 0>
 __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
 {

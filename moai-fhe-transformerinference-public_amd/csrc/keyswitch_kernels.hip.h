@@ -875,9 +875,37 @@ struct StoreModDown
     int use_sc;
     uint32_t splits;       // partial sums to add up (key switch on few ciphertexts), 1 otherwise
     size_t split_stride;   // 16-byte chunks between consecutive partial copies
-    __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 u) const
+    // the operands of four chunks, fetched together (fwd_contig_tile calls fetch before it finishes them): the compiled loop
+    // used to make up to three dependent round trips per chunk -- accumulator, addend, second addend, each behind its own
+    // null-pointer branch and wait -- twenty-four per tile
+    ulonglong2 av[4], cv[4], dv[4];
+    __device__ __forceinline__ void fetch(const uint32_t (&chs)[4])
     {
-        ulonglong2 x = acc[ch], r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            av[i] = acc[chs[i]];
+        }
+        if (add)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                cv[i] = add[chs[i]];
+            }
+        }
+        if (add2)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                dv[i] = add2[chs[i]];
+            }
+        }
+    }
+    __device__ __forceinline__ void operator()(int i, uint32_t ch, ulonglong2 u) const
+    {
+        ulonglong2 x = av[i], r;
         for (uint32_t sp = 1; sp < splits; ++sp)
         {
             ulonglong2 y = acc[ch + sp * split_stride];
@@ -894,15 +922,13 @@ struct StoreModDown
         r.y = csub(mul_shoup_lazy(x.y + q - u.y, inv.w, inv.wq, q), q);
         if (add)
         {
-            ulonglong2 c = add[ch];
-            r.x = csub(r.x + c.x, q);
-            r.y = csub(r.y + c.y, q);
+            r.x = csub(r.x + cv[i].x, q);
+            r.y = csub(r.y + cv[i].y, q);
         }
         if (add2)
         {
-            ulonglong2 c = add2[ch];
-            r.x = csub(r.x + c.x, q);
-            r.y = csub(r.y + c.y, q);
+            r.x = csub(r.x + dv[i].x, q);
+            r.y = csub(r.y + dv[i].y, q);
         }
         out[ch] = r;
     }

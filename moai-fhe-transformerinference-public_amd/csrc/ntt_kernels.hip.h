@@ -417,10 +417,15 @@ __global__ __launch_bounds__(256, (MODE == M_GUARD2 || MODE == M_LAZY8 || MODE =
 // forward, contiguous pass: stages LOGN-8 .. LOGN-1 on 16 consecutive 256-blocks; writes canonical
 // =====================================================================================================
 // what the contiguous pass does with a finished 16-byte chunk (index ch within the 4096-coefficient tile)
+// fetch(chs) is called with four chunk indices before the four calls that finish them: a store operation that needs operands
+// from memory issues all its loads there, in one batch, instead of one round trip per chunk and operand
 struct StoreTile
 {
     ulonglong2 *out; // tile base
-    __device__ __forceinline__ void operator()(uint32_t ch, ulonglong2 v) const
+    __device__ __forceinline__ void fetch(const uint32_t (&)[4])
+    {
+    }
+    __device__ __forceinline__ void operator()(int, uint32_t ch, ulonglong2 v) const
     {
         out[ch] = v;
     }
@@ -531,11 +536,21 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     // every wave stores the 64 rows (8 KiB, contiguous in memory) its own lanes finished: 1 KiB per wave instruction
     const uint32_t wbase = (tid >> 6) << 9, lane = tid & 63u;
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
+    for (int h = 0; h < 2; ++h)
     {
-        uint32_t ch = wbase + (uint32_t)it * 64u + lane;
-        uint32_t rr = ch >> 3;
-        store(ch, lds2[(rr << 3) | ((ch & 7u) ^ (rr & 7u))]);
+        uint32_t chs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            chs[i] = wbase + (uint32_t)(4 * h + i) * 64u + lane;
+        }
+        store.fetch(chs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const uint32_t rr = chs[i] >> 3;
+            store(i, chs[i], lds2[(rr << 3) | ((chs[i] & 7u) ^ (rr & 7u))]);
+        }
     }
 }
 

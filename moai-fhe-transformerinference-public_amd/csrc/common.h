@@ -42,7 +42,10 @@ struct alignas(16) PrimeConst
 // Row -> context-prime map passed by value to kernels (rows of one RNS polynomial).
 struct RowMap
 {
-    uint16_t idx[MOAI_MAX_RNS];
+    // 32-bit entries: a kernel indexes these kernarg arrays with a value it computes (uniform over the workgroup), and gfx950 has
+    // scalar loads for dwords only -- 16-bit entries came through a VECTOR load and a full s_waitcnt vmcnt(0) at the head of every
+    // workgroup (and of every term of the plaintext dot products)
+    uint32_t idx[MOAI_MAX_RNS];
 };
 
 int set_error(int code, const char *fmt, ...);

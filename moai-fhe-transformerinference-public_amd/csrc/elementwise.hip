@@ -704,13 +704,13 @@ struct CtPtDotArgs
     uint64_t *out;       // [n_poly][L][N]
     const PrimeConst *pc;
     uint32_t terms, L, n2, n_poly;
-    uint16_t xi[CTPT_MAX_TERMS];
-    uint16_t pi[CTPT_MAX_TERMS];
+    uint32_t xi[CTPT_MAX_TERMS]; // 32-bit entries: read per term through scalar loads (see RowMap)
+    uint32_t pi[CTPT_MAX_TERMS];
     // a second sum over the leading terms2 <= terms operands with its own plaintexts (moai_ct_pt_dot2): the operands are
     // loaded once for both
     uint64_t *out2;
     uint32_t terms2;
-    uint16_t pi2[CTPT_MAX_TERMS];
+    uint32_t pi2[CTPT_MAX_TERMS];
 };
 
 // P polynomials per thread: a plaintext value is loaded once and multiplied into P ciphertext polynomials (a plaintext row is
@@ -751,14 +751,16 @@ __global__ __launch_bounds__(256) void ct_pt_dot_kernel(CtPtDotArgs g)
     }
     for (uint32_t t = 0; t < g.terms; ++t)
     {
-        const ulonglong2 b = pb[(size_t)g.pi[t] * pt_stride];
+        // the term's three operand indices first (scalar loads, one wait), then its six 16-byte operands in one batch
+        const uint32_t ip = g.pi[t], ip2 = TWO ? g.pi2[t] : 0u, ix = g.xi[t];
+        const ulonglong2 b = pb[(size_t)ip * pt_stride];
         const bool second = TWO && t < g.terms2; // uniform
         ulonglong2 b2 = make_ulonglong2(0, 0);
         if (second)
         {
-            b2 = pb[(size_t)g.pi2[t] * pt_stride];
+            b2 = pb[(size_t)ip2 * pt_stride];
         }
-        const ulonglong2 *xt = xb + (size_t)g.xi[t] * op_stride;
+        const ulonglong2 *xt = xb + (size_t)ix * op_stride;
         ulonglong2 a[P];
 #pragma unroll
         for (int k = 0; k < P; ++k)
@@ -1456,9 +1458,9 @@ static int ct_pt_dot_common(moai_ctx *c, const uint64_t *x, const uint64_t *p, u
         {
             return set_error(MOAI_EINVAL, "operand index out of range");
         }
-        g.xi[t] = (uint16_t)x_index[t];
-        g.pi[t] = (uint16_t)p_index[t];
-        g.pi2[t] = (uint16_t)(out2 && t < terms2 ? p_index2[t] : 0);
+        g.xi[t] = x_index[t];
+        g.pi[t] = p_index[t];
+        g.pi2[t] = out2 && t < terms2 ? p_index2[t] : 0;
     }
     hipStream_t s = (hipStream_t)stream;
     if (n_poly >= 4)

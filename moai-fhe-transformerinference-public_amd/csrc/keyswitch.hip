@@ -343,7 +343,7 @@ static int moddown(moai_ctx *c, uint64_t *last_rows, const uint64_t *acc, uint32
                 }
                 if (m == mode)
                 {
-                    a.sel.idx[a.Lsel++] = (uint16_t)i;
+                    a.sel.idx[a.Lsel++] = (uint32_t)i;
                 }
             }
             if (!a.Lsel)
@@ -707,7 +707,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
         tg.stride_rows = (uint32_t)target_stride_rows;
         tg.off_rows = (uint32_t)target_off_rows;
         tg.key_rows = key_rows;
-        std::vector<uint16_t> order;
+        std::vector<uint32_t> order;
         std::vector<int> order_mode;
         for (int mode = M_FPR; mode >= M_GUARD; --mode)
         {
@@ -716,7 +716,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
                 const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
                 if (ks_mode(c, prime, L, allow_fp) == mode)
                 {
-                    order.push_back((uint16_t)Iidx);
+                    order.push_back((uint32_t)Iidx);
                     order_mode.push_back(mode);
                 }
             }
@@ -733,8 +733,8 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             for (size_t i = 0; i < MOAI_MAX_RNS; ++i)
             {
                 size_t Iidx = order[o0 + (i < g ? i : 0)];
-                grp.prime[i] = (uint16_t)(Iidx == L ? k - 1 : Iidx);
-                grp.slot[i] = (uint16_t)Iidx;
+                grp.prime[i] = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+                grp.slot[i] = (uint32_t)Iidx;
             }
             switch (c->logn)
             {
@@ -772,7 +772,7 @@ static int switch_key_impl(moai_ctx *c, uint64_t *ct, const uint64_t *target, si
             MOAI_LAUNCH_CHECK();
             for (size_t r = 0; r < L; ++r)
             {
-                rm.idx[r] = (uint16_t)prime;
+                rm.idx[r] = (uint32_t)prime;
             }
             rc = ntt_launch(c, ops, batch, L, rm, false, s);
             if (rc)
@@ -1175,7 +1175,7 @@ static void hoist_contig_finish(moai_ctx *c, uint64_t *tmp, size_t L, size_t bat
             {
                 continue; // the strided pass skipped it: the digit under its own prime is read from the ciphertext
             }
-            a.sel.idx[a.Lsel] = (uint16_t)(g * L + J);
+            a.sel.idx[a.Lsel] = (uint32_t)(g * L + J);
             a.selp.idx[a.Lsel++] = grp.prime[g];
         }
         a.total_work = a.n_poly * a.Lsel * tpr;
@@ -1513,7 +1513,7 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
         else
         {
             const bool allow_fp = (long)(batch * L) >= tuning("MOAI_KS_FP_MIN_ROWS", 16);
-            std::vector<uint16_t> order;
+            std::vector<uint32_t> order;
             std::vector<int> order_mode;
             for (int mode = M_FPR; mode >= M_GUARD; --mode)
             {
@@ -1522,7 +1522,7 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
                     const uint32_t prime = (uint32_t)(Iidx == L ? k - 1 : Iidx);
                     if (ks_mode(c, prime, L, allow_fp) == mode)
                     {
-                        order.push_back((uint16_t)Iidx);
+                        order.push_back((uint32_t)Iidx);
                         order_mode.push_back(mode);
                     }
                 }
@@ -1539,8 +1539,8 @@ extern "C" int moai_apply_galois_hoisted(moai_ctx *c, const uint64_t *in, uint64
                 for (size_t i = 0; i < MOAI_MAX_RNS; ++i)
                 {
                     size_t Iidx = order[o0 + (i < g ? i : 0)];
-                    grp.prime[i] = (uint16_t)(Iidx == L ? k - 1 : Iidx);
-                    grp.slot[i] = (uint16_t)Iidx;
+                    grp.prime[i] = (uint32_t)(Iidx == L ? k - 1 : Iidx);
+                    grp.slot[i] = (uint32_t)Iidx;
                 }
                 switch (c->logn)
                 {

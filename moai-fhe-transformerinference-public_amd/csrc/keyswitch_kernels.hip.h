@@ -16,8 +16,8 @@ namespace moai {
 
 struct KsGroup
 {
-    uint16_t prime[MOAI_MAX_RNS]; // context prime of group member g
-    uint16_t slot[MOAI_MAX_RNS];  // row of acc it produces (I, or L for the special prime)
+    uint32_t prime[MOAI_MAX_RNS]; // context prime of group member g (32-bit entries: scalar loads, see RowMap)
+    uint32_t slot[MOAI_MAX_RNS];  // row of acc it produces (I, or L for the special prime)
 };
 
 struct KsP1Args
@@ -818,19 +818,32 @@ __global__ __launch_bounds__(256, 4) void ks_hoisted_mac2(HoistMac2Args a)
                 }
             }
         }
+        // the sixteen correction values first, in one batch: written as load-add-store per accumulator, the compiled epilogue made
+        // sixteen dependent round trips (it cannot see that the stores never touch the correction rows)
+        uint64_t c0v[NR][E], c1v[NR][E];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
         {
-            uint64_t *__restrict__ o0 = a.acc[r] + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN);
-            uint64_t *__restrict__ o1 = a.acc[r] + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN);
             const uint64_t *__restrict__ c0 = a.corr[r] + (((size_t)0 * (a.L + 1) + slot) << LOGN);
             const uint64_t *__restrict__ c1 = a.corr[r] + (((size_t)1 * (a.L + 1) + slot) << LOGN);
 #pragma unroll
             for (int e = 0; e < E; ++e)
             {
+                c0v[r][e] = c0[dst[r][e]];
+                c1v[r][e] = c1[dst[r][e]];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+        {
+            uint64_t *__restrict__ o0 = a.acc[r] + ((((size_t)bq * 2 + 0) * (a.L + 1) + slot) << LOGN);
+            uint64_t *__restrict__ o1 = a.acc[r] + ((((size_t)bq * 2 + 1) * (a.L + 1) + slot) << LOGN);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+            {
                 const uint32_t d = dst[r][e];
-                o0[d] = csub(fp_to_canonical(s0[r][e], qd, qinv) + c0[d], q);
-                o1[d] = csub(fp_to_canonical(s1[r][e], qd, qinv) + c1[d], q);
+                o0[d] = csub(fp_to_canonical(s0[r][e], qd, qinv) + c0v[r][e], q);
+                o1[d] = csub(fp_to_canonical(s1[r][e], qd, qinv) + c1v[r][e], q);
             }
         }
     }

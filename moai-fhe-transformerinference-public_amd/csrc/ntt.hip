@@ -57,7 +57,7 @@ static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
             if (ntt_mode(c, a.rows.idx[r]) == mode)
             {
                 a.selp.idx[a.Lsel] = a.rows.idx[r];
-                a.sel.idx[a.Lsel++] = (uint16_t)r;
+                a.sel.idx[a.Lsel++] = (uint32_t)r;
             }
         }
         if (a.Lsel == 0)
@@ -109,7 +109,7 @@ static void launch_inv(const moai_ctx *c, const NttArgs &base, hipStream_t s)
     {
         NttArgs &dst = (lazy8 && c->primes[base.rows.idx[r]] < (1ull << 60)) ? lo : hi;
         dst.selp.idx[dst.Lsel] = base.rows.idx[r];
-        dst.sel.idx[dst.Lsel++] = (uint16_t)r;
+        dst.sel.idx[dst.Lsel++] = (uint32_t)r;
     }
     if (lo.Lsel)
     {
@@ -239,7 +239,7 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     a.rows = rows;
     for (size_t r = 0; r < MOAI_MAX_RNS; ++r)
     {
-        a.sel.idx[r] = (uint16_t)(r < L ? r : 0);
+        a.sel.idx[r] = (uint32_t)(r < L ? r : 0);
         a.selp.idx[r] = rows.idx[r < L ? r : 0];
     }
     a.Lsel = (uint32_t)L;
@@ -401,7 +401,7 @@ int make_rowmap(const moai_ctx *c, size_t L, const uint32_t *prime_index, RowMap
         {
             return set_error(MOAI_ERANGE, "prime index %u out of range (k = %zu)", p, c->k);
         }
-        out->idx[r] = (uint16_t)p;
+        out->idx[r] = (uint32_t)p;
     }
     for (size_t r = L; r < MOAI_MAX_RNS; r++)
     {

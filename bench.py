@@ -590,7 +590,7 @@ def ntt_moai_chain_region(m, args, torch, np, dev, stream, check):
         "workload": "negacyclic NTT then INTT, N=65536, MOAI's 35 data primes {51, 46x20, 51x14}, %d ciphertexts x 2 polys, FP64-pipe butterflies" % B,
         "value": round(2 * bytes_dir / ((fwd + inv) * 1e-3) / 1e9, 1), "unit": "GB/s",
         "roofline": {
-            "bound": "hbm", "kernel": "forward NTT = ntt_fwd_strided<16,2|3> + ntt_fwd_contig<16,2|3> (exact FP64 butterflies)",
+            "bound": "hbm", "kernel": "forward NTT = ntt_fwd_strided<16,2|3> + ntt_fwd_contig<16,2|3>; inverse = ntt_inv_contig<16,2|3> + ntt_inv_strided<16,2|3> (exact FP64 butterflies both ways)",
             "achieved": round(bytes_dir / (fwd * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(bytes_dir / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
             "fwd_ms": round(fwd, 4), "inv_ms": round(inv, 4), "inv_achieved": round(bytes_dir / (inv * 1e-3) / 1e9, 1),

@@ -116,6 +116,9 @@ struct moai_ctx
     // fwd_twb; rows of primes that have no FP64 mode are zero
     moai::Tw *fwd_twf = nullptr;
     moai::Tw *fwd_twfb = nullptr;
+    // the inverse tables in the same form (inv_tw / inv_twb indexing): the inverse transform of rows below 2^51
+    moai::Tw *inv_twf = nullptr;
+    moai::Tw *inv_twfb = nullptr;
     // the same powers as plain doubles, 8 bytes per entry (fwd_tw indexing): the contiguous key-switch kernel is
     // bound by twiddle fetches and takes its quotient estimate from RN(1/q) instead (modarith.hip.h ct_bfly_fp1)
     double *fwd_twf1 = nullptr;

@@ -509,13 +509,15 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         }
     }
     // FP64 forward tables: {double w, double RN(w / q)} in the two words of a Tw (modarith.hip.h)
-    std::vector<Tw> fwdf, fwdfb;
+    std::vector<Tw> fwdf, fwdfb, invf, invfb;
     std::vector<double> fwdf1;
     if (logn >= 12)
     {
         fwdf1.assign(k * n, 0.0);
         fwdf.assign(k * n, Tw{ 0, 0 });
         fwdfb.assign(k * nb, Tw{ 0, 0 });
+        invf.assign(k * n, Tw{ 0, 0 });
+        invfb.assign(k * nb, Tw{ 0, 0 });
         auto to_fp = [](Tw t, uint64_t q) {
             double w = (double)t.w, wq = (double)t.w / (double)q;
             Tw o;
@@ -533,10 +535,12 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
             {
                 fwdf[p * n + i] = to_fp(fwd[p * n + i], primes[p]);
                 fwdf1[p * n + i] = (double)fwd[p * n + i].w;
+                invf[p * n + i] = to_fp(inv[p * n + i], primes[p]);
             }
             for (size_t i = 0; i < nb; i++)
             {
                 fwdfb[p * nb + i] = to_fp(fwdb[p * nb + i], primes[p]);
+                invfb[p * nb + i] = to_fp(invb[p * nb + i], primes[p]);
             }
         }
     }
@@ -565,6 +569,10 @@ extern "C" int moai_ctx_create(int logn, const uint64_t *primes, size_t k, int d
         (nb && (e = hipMalloc(&c->fwd_twfb, sizeof(Tw) * k * nb)) != hipSuccess) ||
         (nb && (e = hipMemcpy(c->fwd_twf, fwdf.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess) ||
         (nb && (e = hipMemcpy(c->fwd_twfb, fwdfb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (nb && (e = hipMalloc(&c->inv_twf, sizeof(Tw) * k * n)) != hipSuccess) ||
+        (nb && (e = hipMalloc(&c->inv_twfb, sizeof(Tw) * k * nb)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->inv_twf, invf.data(), sizeof(Tw) * k * n, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(c->inv_twfb, invfb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
         (nb && (e = hipMalloc(&c->fwd_twb, sizeof(Tw) * k * nb)) != hipSuccess) ||
         (nb && (e = hipMalloc(&c->inv_twb, sizeof(Tw) * k * nb)) != hipSuccess) ||
         (nb && (e = hipMemcpy(c->fwd_twb, fwdb.data(), sizeof(Tw) * k * nb, hipMemcpyHostToDevice)) != hipSuccess) ||
@@ -596,6 +604,8 @@ extern "C" void moai_ctx_destroy(moai_ctx *c)
     (void)hipFree(c->fwd_twf);
     (void)hipFree(c->fwd_twf1);
     (void)hipFree(c->fwd_twfb);
+    (void)hipFree(c->inv_twf);
+    (void)hipFree(c->inv_twfb);
     (void)hipFree(c->fwd_twb);
     (void)hipFree(c->inv_twb);
     for (auto &kv : c->ws)

@@ -334,4 +334,57 @@ __device__ __forceinline__ void gs_bfly_sel<true>(uint64_t &x, uint64_t &y, uint
     gs_bfly_lazy8(x, y, w, wq, a, b);
 }
 
+// ---- inverse transform in exact FP64 arithmetic (primes below 2^51; the scheme of the forward M_FPN / M_FPR modes) ----------
+// Gentleman-Sande butterfly on doubles holding integers: x' = u + v, y' = (u - v) w mod q with the product reduced at once
+// (fp_mulmod: exact for |u - v| < 2^52).  The sums double from stage to stage, the products come out below 1.5 q:
+//   FPR  (q < 2^51, 2^53 > 4q): sum and difference are reduced in every butterfly (inputs below q, outputs below 0.75 q);
+//   FPN  (q < 2^52 / 25): `redsum` reduces the sum in every FOURTH stage of a pass -- from 1q the sums reach 8q, the differences
+//        16q < 2^52 -- and the last stage of the transform multiplies both outputs by N^-1 (gs_bfly_last_fp).
+// Same exact integers as the integer butterflies, canonical at the end (fp_to_canonical): the reference's residues.
+template <bool FPR>
+__device__ __forceinline__ void gs_bfly_fp(uint64_t &xb, uint64_t &yb, uint64_t wb, uint64_t wqb, uint64_t qb, uint64_t qinvb, const bool redsum)
+{
+    const double q = u2d(qb), qi = u2d(qinvb);
+    const double u = u2d(xb), v = u2d(yb);
+    double s = u + v, d = u - v;
+    if (FPR)
+    {
+        s = fp_red(s, q, qi);
+        d = fp_red(d, q, qi);
+    }
+    else if (redsum)
+    {
+        s = fp_red(s, q, qi);
+    }
+    xb = d2u(s);
+    yb = d2u(fp_mulmod(d, u2d(wb), u2d(wqb), q));
+}
+// last stage: x' = (u + v) N^-1, y' = (u - v) (N^-1 w_1); the constants as plain doubles, quotient from RN(1/q)
+template <bool FPR>
+__device__ __forceinline__ void gs_bfly_last_fp(uint64_t &xb, uint64_t &yb, double ninv, double ninv_w1, double q, double qi)
+{
+    const double u = u2d(xb), v = u2d(yb);
+    double s = u + v, d = u - v;
+    if (FPR)
+    {
+        s = fp_red(s, q, qi);
+        d = fp_red(d, q, qi);
+    }
+    xb = d2u(fp_mulmod_q(s, ninv, q, qi));
+    yb = d2u(fp_mulmod_q(d, ninv_w1, q, qi));
+}
+// IM: 0 exact integer [0, 2q), 1 M_LAZY8, 2 FPN, 3 FPR; (a, b) = the mode's two constants
+template <int IM>
+__device__ __forceinline__ void gs_bfly_im(uint64_t &x, uint64_t &y, uint64_t w, uint64_t wq, uint64_t a, uint64_t b, const bool redsum)
+{
+    if (IM >= 2)
+    {
+        gs_bfly_fp<IM == 3>(x, y, w, wq, a, b, redsum);
+    }
+    else
+    {
+        gs_bfly_sel<IM == 1>(x, y, w, wq, a, b);
+    }
+}
+
 } // namespace moai

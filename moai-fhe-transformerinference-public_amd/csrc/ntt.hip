@@ -96,33 +96,45 @@ static void launch_fwd(const moai_ctx *c, const NttArgs &base, hipStream_t s)
     }
 }
 
-// inverse transform: rows of primes below 2^60 take the butterflies with the approximate Shoup quotient (M_LAZY8,
-// modarith.hip.h), the others the exact ones; one pair of launches per class, same residues
+// inverse transform: rows of primes below 2^51 run in exact FP64 arithmetic like the forward transform (FPN / FPR, modarith.hip.h
+// gs_bfly_fp; MOAI_NTT_FP=0 keeps them on the integer units), rows of primes below 2^60 take the integer butterflies with the
+// approximate Shoup quotient (M_LAZY8), the others the exact ones; one pair of launches per class, same residues
+template <int LOGN, int IM>
+static void launch_inv_class(NttArgs a, hipStream_t s)
+{
+    constexpr uint32_t tpr = 1u << (LOGN - 12);
+    if (!a.Lsel)
+    {
+        return;
+    }
+    a.total_work = a.n_poly * a.Lsel * tpr;
+    hipLaunchKernelGGL((ntt_inv_contig<LOGN, IM>), dim3(a.total_work), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((ntt_inv_strided<LOGN, IM>), dim3(a.total_work), dim3(256), 0, s, a);
+}
+
 template <int LOGN>
 static void launch_inv(const moai_ctx *c, const NttArgs &base, hipStream_t s)
 {
     static const long lazy8 = env_long("MOAI_NTT_LAZY8", 1);
-    constexpr uint32_t tpr = 1u << (LOGN - 12);
-    NttArgs lo = base, hi = base;
-    lo.Lsel = hi.Lsel = 0;
+    NttArgs cls[4] = { base, base, base, base }; // exact, lazy8, FPN, FPR
+    for (NttArgs &a : cls)
+    {
+        a.Lsel = 0;
+    }
+    cls[2].tw = cls[3].tw = c->inv_twf;
+    cls[2].twb = cls[3].twb = c->inv_twfb;
     for (uint32_t r = 0; r < base.L; ++r)
     {
-        NttArgs &dst = (lazy8 && c->primes[base.rows.idx[r]] < (1ull << 60)) ? lo : hi;
-        dst.selp.idx[dst.Lsel] = base.rows.idx[r];
-        dst.sel.idx[dst.Lsel++] = (uint32_t)r;
+        const uint32_t prime = base.rows.idx[r];
+        const int m = ntt_mode(c, prime);
+        NttArgs &dst = m == M_FPN ? cls[2] : (m == M_FPR ? cls[3] : ((lazy8 && c->primes[prime] < (1ull << 60)) ? cls[1] : cls[0]));
+        dst.selp.idx[dst.Lsel] = prime;
+        dst.sel.idx[dst.Lsel++] = r;
     }
-    if (lo.Lsel)
-    {
-        lo.total_work = lo.n_poly * lo.Lsel * tpr;
-        hipLaunchKernelGGL((ntt_inv_contig<LOGN, true>), dim3(lo.total_work), dim3(256), 0, s, lo);
-        hipLaunchKernelGGL((ntt_inv_strided<LOGN, true>), dim3(lo.total_work), dim3(256), 0, s, lo);
-    }
-    if (hi.Lsel)
-    {
-        hi.total_work = hi.n_poly * hi.Lsel * tpr;
-        hipLaunchKernelGGL((ntt_inv_contig<LOGN, false>), dim3(hi.total_work), dim3(256), 0, s, hi);
-        hipLaunchKernelGGL((ntt_inv_strided<LOGN, false>), dim3(hi.total_work), dim3(256), 0, s, hi);
-    }
+    launch_inv_class<LOGN, 0>(cls[0], s);
+    launch_inv_class<LOGN, 1>(cls[1], s);
+    launch_inv_class<LOGN, 2>(cls[2], s);
+    launch_inv_class<LOGN, 3>(cls[3], s);
 }
 
 } // namespace moai

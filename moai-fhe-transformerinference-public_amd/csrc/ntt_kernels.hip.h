@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 // inverse, contiguous pass: stages LOGN-1 .. LOGN-8 (gap 1 .. 128); lazy [0,2q) out
 // =====================================================================================================
 // LZ: the M_LAZY8 butterflies (modarith.hip.h), with (q, q2) = (2^64 - q, 2^64 - 4q); values below 4q instead of 2q
-template <int LOGN, bool LZ = false>
+// IM: 0 exact integer butterflies, 1 M_LAZY8, 2 / 3 exact FP64 (FPN / FPR, modarith.hip.h gs_bfly_fp: canonical integers in,
+// doubles out to the strided pass; tw / twb = the FP64 inverse tables, (q, q2) = the bit patterns of (double q, 1/q))
+template <int LOGN, int IM = 0>
 __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
                                                 const Tw *__restrict__ twb, const uint64_t *srcp = nullptr)
@@ -625,8 +627,8 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
     for (int c = 0; c < 8; ++c)
     {
         ulonglong2 v = lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))];
-        x[2 * c] = v.x;
-        x[2 * c + 1] = v.y;
+        x[2 * c] = IM >= 2 ? d2u(fp_from_u52(v.x)) : v.x;
+        x[2 * c + 1] = IM >= 2 ? d2u(fp_from_u52(v.y)) : v.y;
     }
 #pragma unroll
     for (int u = 7; u >= 4; --u)
@@ -638,7 +640,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
             if (!(j & half))
             {
                 Tw t = tb[(1 << (u - 4)) - 1 + (j >> (8 - u))];
-                gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
+                gs_bfly_im<IM>(x[j], x[j + half], t.w, t.wq, q, q2, (u & 3) == 0); // FPN: sums folded in every fourth stage
             }
         }
     }
@@ -667,7 +669,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
             if (!(j & half))
             {
                 Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
-                gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
+                gs_bfly_im<IM>(x[j], x[j + half], t.w, t.wq, q, q2, (u & 3) == 0); // FPN: sums folded in every fourth stage
             }
         }
     }
@@ -678,7 +680,7 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
     }
 }
 
-template <int LOGN, bool LZ = false>
+template <int LOGN, int IM = 0>
 __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
@@ -691,23 +693,25 @@ __global__ __launch_bounds__(256) void ntt_inv_contig(NttArgs a)
     const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[rest / TPR]);
     const PrimeConst &pc = a.pc[prime];
     const uint64_t *srcp = a.src ? a.src + (((size_t)pol * a.src_stride + a.src_off + r) << LOGN) : nullptr;
-    inv_contig_tile<LOGN, LZ>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN), LZ ? pc.nq : pc.q,
-                              LZ ? pc.n4q : pc.q2, lds2, threadIdx.x, a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), srcp);
+    inv_contig_tile<LOGN, IM>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
+                              IM >= 2 ? pc.qd : (IM == 1 ? pc.nq : pc.q), IM >= 2 ? pc.qinv : (IM == 1 ? pc.n4q : pc.q2), lds2, threadIdx.x,
+                              a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), srcp);
 }
 
 // =====================================================================================================
 // inverse, strided pass: stages LOGN-9 .. 0, N^-1 folded into stage 0; writes canonical
 // =====================================================================================================
-template <int LOGN, bool LZ = false>
+template <int LOGN, int IM = 0>
 __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                  const PrimeConst *pc, uint64_t *lds, const uint32_t tid)
 {
+    constexpr bool LZ = (IM == 1);
     constexpr int R1 = LOGN - 8;
     constexpr int RB = R1 - 4;
     constexpr int GB = 12 - R1;
     constexpr uint32_t G = 1u << GB;
-    const uint64_t q = LZ ? pc->nq : pc->q;
-    const uint64_t q2 = LZ ? pc->n4q : pc->q2;
+    const uint64_t q = IM >= 2 ? pc->qd : (LZ ? pc->nq : pc->q);
+    const uint64_t q2 = IM >= 2 ? pc->qinv : (LZ ? pc->n4q : pc->q2);
     uint64_t *__restrict__ row = rowp + tile * G;
 
     uint64_t x[16];
@@ -732,7 +736,7 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
                 {
                     uint32_t t_ = (th << 4) | (uint32_t)j;
                     Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
-                    gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
+                    gs_bfly_im<IM>(x[j], x[j + half], t.w, t.wq, q, q2, ((R1 - 1 - s) & 3) == 3); // stage number in this pass
                 }
             }
         }
@@ -767,7 +771,7 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
             if (!(j & half))
             {
                 Tw t = tw[(1u << u) + (uint32_t)(j >> (4 - u))];
-                gs_bfly_sel<LZ>(x[j], x[j + half], t.w, t.wq, q, q2);
+                gs_bfly_im<IM>(x[j], x[j + half], t.w, t.wq, q, q2, ((RB + 3 - u) & 3) == 3);
             }
         }
     }
@@ -777,7 +781,11 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
 #pragma unroll
         for (int j = 0; j < 8; ++j)
         {
-            if (LZ)
+            if (IM >= 2)
+            {
+                gs_bfly_last_fp<IM == 3>(x[j], x[j + 8], fp_from_u64(ninv.w), fp_from_u64(ninv_w1.w), u2d(q), u2d(q2));
+            }
+            else if (LZ)
             {
                 gs_bfly_last_lazy8(x[j], x[j + 8], ninv, ninv_w1, q, q2);
             }
@@ -792,12 +800,13 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
     {
         uint32_t e = (uint32_t)j * 256u + tid;
         // exact: below 2q; LZ: below 4q, with 2^64 - 2q = (2^64 - 4q) / 2 + 2^63
-        row[((e >> GB) << 8) + (e & (G - 1))] = LZ ? csub_sign(csub_sign(x[j], (q2 >> 1) | 0x8000000000000000ull), q) : csub(x[j], q);
+        row[((e >> GB) << 8) + (e & (G - 1))] = IM >= 2 ? fp_to_canonical(u2d(x[j]), u2d(q), u2d(q2))
+                                                        : (LZ ? csub_sign(csub_sign(x[j], (q2 >> 1) | 0x8000000000000000ull), q) : csub(x[j], q));
     }
 }
 
-template <int LOGN, bool LZ = false>
-__global__ __launch_bounds__(256, LZ ? 4 : 5) void ntt_inv_strided(NttArgs a)
+template <int LOGN, int IM = 0>
+__global__ __launch_bounds__(256, IM == 1 ? 4 : 5) void ntt_inv_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
     __shared__ uint64_t lds[4096];
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(256, LZ ? 4 : 5) void ntt_inv_strided(NttArgs a)
     const uint32_t si = srow % a.Lsel;
     const uint32_t r = __builtin_amdgcn_readfirstlane(a.sel.idx[si]);
     const uint32_t prime = __builtin_amdgcn_readfirstlane(a.selp.idx[si]);
-    inv_strided_tile<LOGN, LZ>(a.data + ((size_t)((srow / a.Lsel) * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc + prime, lds,
+    inv_strided_tile<LOGN, IM>(a.data + ((size_t)((srow / a.Lsel) * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN), a.pc + prime, lds,
                                threadIdx.x);
 }
 

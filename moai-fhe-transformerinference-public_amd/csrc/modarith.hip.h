@@ -338,8 +338,9 @@ __device__ __forceinline__ void gs_bfly_sel<true>(uint64_t &x, uint64_t &y, uint
 // Gentleman-Sande butterfly on doubles holding integers: x' = u + v, y' = (u - v) w mod q with the product reduced at once
 // (fp_mulmod: exact for |u - v| < 2^52).  The sums double from stage to stage, the products come out below 1.5 q:
 //   FPR  (q < 2^51, 2^53 > 4q): sum and difference are reduced in every butterfly (inputs below q, outputs below 0.75 q);
-//   FPN  (q < 2^52 / 25): `redsum` reduces the sum in every FOURTH stage of a pass -- from 1q the sums reach 8q, the differences
-//        16q < 2^52 -- and the last stage of the transform multiplies both outputs by N^-1 (gs_bfly_last_fp).
+//   FPN  (q < 2^52 / 25): `redsum` reduces the sum in every FOURTH stage of a pass -- from q/2 (the load folds the input) or from
+//        the ~1.2 q of a product the sums stay below 10q, the differences below 19q (below 2^52, as 25q is) -- and the last stage of the transform
+//        multiplies both outputs by N^-1 (gs_bfly_last_fp).
 // Same exact integers as the integer butterflies, canonical at the end (fp_to_canonical): the reference's residues.
 template <bool FPR>
 __device__ __forceinline__ void gs_bfly_fp(uint64_t &xb, uint64_t &yb, uint64_t wb, uint64_t wqb, uint64_t qb, uint64_t qinvb, const bool redsum)

@@ -627,8 +627,10 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
     for (int c = 0; c < 8; ++c)
     {
         ulonglong2 v = lds2[(myrow << 3) | ((uint32_t)c ^ (myrow & 7u))];
-        x[2 * c] = IM >= 2 ? d2u(fp_from_u52(v.x)) : v.x;
-        x[2 * c + 1] = IM >= 2 ? d2u(fp_from_u52(v.y)) : v.y;
+        // FP64 modes: any input below 2^52 (canonical or lazy, like the integer butterflies accept); FPN folds it to |.| <= q/2
+        // here -- its schedule of sum reductions counts from there --, FPR folds in every butterfly anyway
+        x[2 * c] = IM == 2 ? d2u(fp_red(fp_from_u52(v.x), u2d(q), u2d(q2))) : (IM == 3 ? d2u(fp_from_u52(v.x)) : v.x);
+        x[2 * c + 1] = IM == 2 ? d2u(fp_red(fp_from_u52(v.y), u2d(q), u2d(q2))) : (IM == 3 ? d2u(fp_from_u52(v.y)) : v.y);
     }
 #pragma unroll
     for (int u = 7; u >= 4; --u)

@@ -854,6 +854,16 @@ def test_fp64_modes_at_their_size_limits(moai):
         d = up(moai, lazy)
         ctx.ntt_forward(d, 3, k)
         assert (d.to_numpy(x.shape) == octx.ntt(x, k)).all()  # same residues as the canonical input
+        # inverse NTT (FP64 Gentleman-Sande butterflies below 2^51): the same extremes, and lazy inputs below 2q
+        d = up(moai, x)
+        ctx.ntt_inverse(d, 3, k)
+        assert (d.to_numpy(x.shape) == octx.ntt(x, k, inverse=True)).all()
+        lazy = x.copy()
+        for i, q in enumerate(primes):
+            lazy[2, i, :] = (lazy[2, i, :] + np.uint64(q)) if q < (1 << 51) else lazy[2, i, :]
+        d = up(moai, lazy)
+        ctx.ntt_inverse(d, 3, k)
+        assert (d.to_numpy(x.shape) == octx.ntt(x, k, inverse=True)).all()
         # key switch with every digit and key residue at q - 1, then random
         for trial in range(3):
             key = O.uniform_rns(rng, primes, (k - 1, 2), n)

@@ -276,8 +276,9 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             for (int c = 0; c < 4; ++c)
             {
                 ulonglong2 v = trow[c];
-                x[2 * c] = v.x;
-                x[2 * c + 1] = v.y;
+                // FP64 modes: as doubles, like the values the butterflies leave (canonical below q: nothing to fold)
+                x[2 * c] = MODE >= M_FPN ? d2u(fp_from_u52(v.x)) : v.x;
+                x[2 * c + 1] = MODE >= M_FPN ? d2u(fp_from_u52(v.y)) : v.y;
             }
         }
         else
@@ -383,7 +384,11 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
         const bool fold = MODE == M_FPR ? ((J - j0) % 3u == 2u) : (((J - j0) & 15u) == 15u);
         if (MODE >= M_FPN && PF != 0)
         {
-            // the same products and sums as below, in the same order per accumulator: the same bits
+            // the same products and sums as below, in the same order per accumulator: the same bits.
+            // The digit value enters the products as the butterflies left it in M_FPN (below 33q < 2^52: the quotient estimate of
+            // fp_mulmod_q is then off by at most 2, the product below 2.5 q, h - c q = r - l still an integer below 2^50, and
+            // sixteen of them on a folded sum stay below 40.5 q < 2^53 = 50 q at least) and folded to |v| <= q/2 in M_FPR
+            // (2^53 is only 4q there).  A copied digit (canonical, below q) needs no folding in either mode.
             const double qd = u2d(bq1), qinv = u2d(bq2);
             if (PF == 1)
             {
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-                const double vx = fp_red(direct ? fp_from_u52(x[2 * c]) : u2d(x[2 * c]), qd, qinv);
-                const double vy = fp_red(direct ? fp_from_u52(x[2 * c + 1]) : u2d(x[2 * c + 1]), qd, qinv);
+                const double vx = MODE == M_FPN ? u2d(x[2 * c]) : fp_red(u2d(x[2 * c]), qd, qinv);
+                const double vy = MODE == M_FPN ? u2d(x[2 * c + 1]) : fp_red(u2d(x[2 * c + 1]), qd, qinv);
                 sm[4 * c + 0] = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kpa[c].x), qd, qinv);
                 sm[4 * c + 1] = u2d(lo0[2 * c + 1]) + fp_mulmod_q(vy, fp_from_u52(kpa[c].y), qd, qinv);
                 sm[4 * c + 2] = u2d(lo1[2 * c]) + fp_mulmod_q(vx, fp_from_u52(kpb[c].x), qd, qinv);
@@ -424,15 +429,15 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
         }
         else if (MODE >= M_FPN)
         {
-            // FP64 modes: the MAC stays on the FP64 pipe as well.  The digit is reduced to |v| <= q/2 so that
-            // h * (1/q) estimates the quotient of v * key within 0.9 (key canonical, below 2^51), each product
-            // is reduced exactly like a butterfly's, and the running sums stay far below 2^52.
+            // FP64 modes: the MAC stays on the FP64 pipe as well (fp_mulmod_q with the key residue canonical, below 2^51; the
+            // digit folded to |v| <= q/2 first in M_FPR, as it comes in M_FPN -- bounds above), each product is reduced
+            // exactly like a butterfly's, and the running sums stay below 2^53.
             const double qd = u2d(bq1), qinv = u2d(bq2);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-                const double vx = fp_red(direct ? fp_from_u52(x[2 * c]) : u2d(x[2 * c]), qd, qinv);
-                const double vy = fp_red(direct ? fp_from_u52(x[2 * c + 1]) : u2d(x[2 * c + 1]), qd, qinv);
+                const double vx = MODE == M_FPN ? u2d(x[2 * c]) : fp_red(u2d(x[2 * c]), qd, qinv);
+                const double vy = MODE == M_FPN ? u2d(x[2 * c + 1]) : fp_red(u2d(x[2 * c + 1]), qd, qinv);
                 const ulonglong2 ka = k0[c];
                 const ulonglong2 kb = k1[c];
                 double s0 = u2d(lo0[2 * c]) + fp_mulmod_q(vx, fp_from_u52(ka.x), qd, qinv);

@@ -75,6 +75,11 @@ int moai_free(void *dptr);
 int moai_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
 int moai_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
 int moai_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+/* n <= 64 separate device blocks of `words` 64-bit words (even) each <-> one packed array [n][words], in ONE launch: what the shim's
+ * call combiner does around a batched operation (it used to enqueue one copy per caller and direction).  src / dst: HOST arrays of
+ * device pointers.  No counterpart in the reference (plumbing of SURVEY 8 row f4). */
+int moai_gather_blocks(moai_ctx *ctx, const uint64_t *const *src, uint64_t *packed, size_t n, size_t words, void *stream);
+int moai_scatter_blocks(moai_ctx *ctx, const uint64_t *packed, uint64_t *const *dst, size_t n, size_t words, void *stream);
 int moai_memset_zero(void *dst, size_t bytes, void *stream);
 int moai_stream_create(void **stream);
 int moai_stream_destroy(void *stream);

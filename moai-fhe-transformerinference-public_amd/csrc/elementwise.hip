@@ -1494,6 +1494,97 @@ static int ct_pt_dot_common(moai_ctx *c, const uint64_t *x, const uint64_t *p, u
     return MOAI_OK;
 }
 
+// ---- n separate blocks <-> one packed array (the call combiner's gather and scatter) --------------------------------------
+struct BlockPtrArgs
+{
+    uint64_t *blk[64];
+    uint64_t *packed;
+    uint32_t n2; // 16-byte chunks per block
+};
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void block_copy_kernel(BlockPtrArgs g)
+{
+    ulonglong2 *b = reinterpret_cast<ulonglong2 *>(g.blk[blockIdx.y]);
+    ulonglong2 *p = reinterpret_cast<ulonglong2 *>(g.packed) + (size_t)blockIdx.y * g.n2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < g.n2; i += gridDim.x * 256u)
+    {
+        if (GATHER)
+        {
+            p[i] = b[i];
+        }
+        else
+        {
+            b[i] = p[i];
+        }
+    }
+}
+
+static int block_copy(moai_ctx *c, uint64_t *const *blocks, uint64_t *packed, size_t n, size_t words, bool gather, void *stream)
+{
+    if (!c)
+    {
+        return set_error(MOAI_EINVAL, "null context");
+    }
+    if (n == 0 || words == 0)
+    {
+        return MOAI_OK;
+    }
+    if (!blocks || !packed)
+    {
+        return set_error(MOAI_EINVAL, "null argument");
+    }
+    if (n > 64 || (words & 1u) || (words >> 1) > 0xffffffffull)
+    {
+        return set_error(MOAI_EINVAL, "at most 64 blocks of an even number of words");
+    }
+    int rc = enter_device(c);
+    if (rc)
+    {
+        return rc;
+    }
+    BlockPtrArgs g;
+    for (size_t i = 0; i < 64; ++i)
+    {
+        g.blk[i] = blocks[i < n ? i : 0];
+        if (i < n && !blocks[i])
+        {
+            return set_error(MOAI_EINVAL, "null block");
+        }
+        if (i < n)
+        {
+            MOAI_AUDIT(stream, blocks[i]);
+        }
+    }
+    g.packed = packed;
+    g.n2 = (uint32_t)(words >> 1);
+    uint32_t bx = (g.n2 + 255u) / 256u;
+    bx = bx > 64u ? 64u : bx;
+    dim3 grid(bx, (uint32_t)n);
+    if (gather)
+    {
+        hipLaunchKernelGGL(block_copy_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    }
+    else
+    {
+        hipLaunchKernelGGL(block_copy_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    }
+    MOAI_LAUNCH_CHECK();
+    return MOAI_OK;
+}
+
+extern "C" int moai_gather_blocks(moai_ctx *c, const uint64_t *const *src, uint64_t *packed, size_t n, size_t words, void *stream)
+{
+    MOAI_AUDIT(stream, packed);
+    return block_copy(c, const_cast<uint64_t *const *>(src), packed, n, words, true, stream);
+}
+
+extern "C" int moai_scatter_blocks(moai_ctx *c, const uint64_t *packed, uint64_t *const *dst, size_t n, size_t words, void *stream)
+{
+    MOAI_AUDIT(stream, packed);
+    return block_copy(c, dst, const_cast<uint64_t *>(packed), n, words, false, stream);
+}
+
 extern "C" int moai_ct_pt_dot(moai_ctx *c, const uint64_t *x, const uint64_t *p, uint64_t *out, const uint32_t *x_index,
                               const uint32_t *p_index, size_t terms, size_t n_poly, size_t L, void *stream)
 {

@@ -79,6 +79,8 @@ SYMBOLS = {
     "moai_scalar_dot": (C.c_int, [vp, C.POINTER(vp), u64p, sz, vp, vp, sz, sz, vp]),
     "moai_vector_dot": (C.c_int, [vp, C.POINTER(vp), vp, sz, vp, vp, sz, sz, vp]),
     "moai_ct_dot_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), sz, vp, vp, sz, vp]),
+    "moai_gather_blocks": (C.c_int, [vp, C.POINTER(vp), vp, sz, sz, vp]),
+    "moai_scatter_blocks": (C.c_int, [vp, vp, C.POINTER(vp), sz, sz, vp]),
     "moai_key_words": (sz, [vp, sz]),
     "moai_key_trim": (C.c_int, [vp, vp, sz, vp, vp]),
     "moai_key_forget": (C.c_int, [vp, vp]),
@@ -341,6 +343,18 @@ class Context:
         ax = (vp * T)(*[_ptr(x) for x in xs])
         ay = (vp * T)(*[_ptr(y) for y in ys])
         _check(lib().moai_ct_dot_ptrs(self.h, ax, ay, T, _ptr(base), _ptr(out), L, stream))
+
+    def gather_blocks(self, blocks, packed, words, stream=None):
+        """packed[i] = blocks[i] (`words` 64-bit words each) in one launch"""
+        n = len(blocks)
+        arr = (vp * n)(*[_ptr(b) for b in blocks])
+        _check(lib().moai_gather_blocks(self.h, arr, _ptr(packed), n, words, stream))
+
+    def scatter_blocks(self, packed, blocks, words, stream=None):
+        """blocks[i] = packed[i] in one launch"""
+        n = len(blocks)
+        arr = (vp * n)(*[_ptr(b) for b in blocks])
+        _check(lib().moai_scatter_blocks(self.h, _ptr(packed), arr, n, words, stream))
 
     def key_trim(self, full_key, levels, stream=None):
         """the part of a key a switch at <= `levels` data primes reads, as a DeviceBuffer [levels][2][levels+1][N] whose layout the

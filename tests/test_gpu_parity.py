@@ -1175,3 +1175,27 @@ def test_ct_dot_ptrs_is_the_chain_of_multiply_and_add(moai, logn, bits, L, terms
     dacc = up(moai, base)
     ctx.ct_dot_ptrs(dxs, dys, dacc, dacc, L)
     assert (dacc.to_numpy((3, L, n)) == np.asarray(octx.add(base, want, 3, L)).reshape(3, L, n)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_blocks,words", [(1, 2), (7, 4096 * 3), (64, 2 * 65536)])
+def test_gather_and_scatter_blocks_copy_every_word(moai, n_blocks, words):
+    """moai_gather_blocks / moai_scatter_blocks (the call combiner's packing around a batched operation): separate blocks -> one
+    packed array and back in one launch each, every word; 65 blocks and an odd word count are refused."""
+    primes = O.coeff_modulus_create(4096, [40, 40])
+    ctx = moai.Context(12, primes)
+    rng = np.random.default_rng(n_blocks)
+    data = [rng.integers(0, 1 << 63, size=words, dtype=np.uint64) for _ in range(n_blocks)]
+    blocks = [up(moai, d) for d in data]
+    packed = moai.DeviceBuffer(n_blocks * words)
+    ctx.gather_blocks(blocks, packed, words)
+    assert (packed.to_numpy((n_blocks, words)) == np.stack(data)).all()
+    fresh = rng.integers(0, 1 << 63, size=(n_blocks, words), dtype=np.uint64)
+    packed2 = up(moai, fresh)
+    ctx.scatter_blocks(packed2, blocks, words)
+    for i in range(n_blocks):
+        assert (blocks[i].to_numpy((words,)) == fresh[i]).all()
+    with pytest.raises(Exception):
+        ctx.gather_blocks(blocks[:1] * 65, packed, 2)
+    with pytest.raises(Exception):
+        ctx.gather_blocks(blocks[:1], packed, 3)

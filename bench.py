@@ -379,6 +379,7 @@ def end_to_end_slice(args, cores):
         "bootstrap_max_error": child["bootstrap_max_error"],
         "bootstrap_chain_index_after": child["bootstrap_chain_index_after"],
         "head_s": child["head_s"],
+        "head_second_s": child.get("head_second_s"),
         "head_max_error": child["head_max_error"],
         "head_max_error_vs_exact_softmax": child["head_max_error_vs_exact_softmax"],
         "child_wall_s": round(time.perf_counter() - t0, 1),
@@ -411,7 +412,10 @@ def end_to_end_slice(args, cores):
     if layer and layer.get("complete"):
         per_input = lambda layer_s: round(12 * layer_s / 256 * 1e3, 1)
         out["layer_s"] = layer["layer_s"]
-        heads_unchanged = 12 * out["head_s"]
+        # twelve heads of a layer through MOAI's unchanged header: the first one as measured (it also pays the process's first
+        # allocations and hoisting corrections), the other eleven like the second head measured on the same inputs
+        h2 = out.get("head_second_s")
+        heads_unchanged = out["head_s"] + 11 * h2 if h2 and h2 > 0 else 12 * out["head_s"]
         out["ms_per_input"] = {
             "fused_callers": {
                 "value": per_input(layer["layer_s"]),
@@ -419,8 +423,9 @@ def end_to_end_slice(args, cores):
                         "layernorm / gelu_v2 headers on packed ciphertexts, packed bootstrapping) / 256 inputs"},
             "unchanged_attention_fused_ffn": {
                 "value": per_input(layer["layer_s"] - layer["attention_s"] + heads_unchanged),
-                "what": "the same layer with its attention (%.1f s) replaced by 12 x the head measured through MOAI's unchanged "
-                        "single_att_block.hpp (%.2f s each)" % (layer["attention_s"], out["head_s"])},
+                "what": "the same layer with its attention (%.1f s) replaced by twelve heads through MOAI's unchanged single_att_block.hpp: "
+                        "%.2f s for the first + 11 x %.2f s (a second head measured on the same inputs)"
+                        % (layer["attention_s"], out["head_s"], h2 if h2 and h2 > 0 else out["head_s"])},
         }
         u = out.get("unchanged_ffn_per_layer_s")
         if u:

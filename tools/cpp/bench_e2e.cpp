@@ -427,9 +427,14 @@ static int run(int argc, char **argv)
         {
             vector<Ciphertext> X = inputs_at(gelu_cts, 8), out(gelu_cts);
             t0 = now_s();
+            // :884-888: 96 parallel iterations x 32 ciphertexts each in the reference, i.e. every host thread busy with its own
+            // sequence of gelu_v2 calls.  The slice keeps that shape -- one iteration per host thread, gelu_cts / threads
+            // ciphertexts each -- so that as many callers are in flight as in the full loop (with 128 / 32 = 4 iterations only
+            // four threads worked and the scaled figure overstated the full loop's time)
+            const int outer = min(threads, gelu_cts), inner = gelu_cts / outer;
 #pragma omp parallel for
-            for (int i = 0; i < gelu_cts / 32; i++) // :884-888: 96 x 32 in the reference
-                for (int j = 0; j < 32; j++) out[i * 32 + j] = gelu_v2(X[i * 32 + j], context, relin_keys, secret_key);
+            for (int i = 0; i < outer; i++)
+                for (int j = 0; j < inner; j++) out[i * inner + j] = gelu_v2(X[i * inner + j], context, relin_keys, secret_key);
             context.sync();
             ffn_gelu_s = now_s() - t0;
         }

@@ -1168,6 +1168,7 @@ static void hoist_contig_finish(moai_ctx *c, uint64_t *tmp, size_t L, size_t bat
         a.pc = c->pc;
         a.L = (uint32_t)(G * L);
         a.n_poly = (uint32_t)batch;
+        a.lds_twiddles = tuning("MOAI_NTT_LDSTW", 1) ? 1u : 0u;
         a.Lsel = 0;
         for (size_t J = 0; J < L; ++J)
         {

@@ -1030,6 +1030,8 @@ template <int LOGN, int MODE>
 __global__ __launch_bounds__(256) void moddown_contig(ModDownArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
+    // (the first four stages' twiddles through LDS, as in ntt_fwd_contig, measured slower here -- 756 against 716-739 us per launch:
+    // 36 KiB of LDS per workgroup leave four of them on a CU where this kernel's 93 registers allow five)
     __shared__ ulonglong2 lds2[2048];
     // polynomial fastest: the workgroups that share a twiddle slice run together
     uint32_t w = xcd_remap(blockIdx.x, a.total_work);

@@ -260,6 +260,8 @@ int ntt_launch(moai_ctx *c, uint64_t *data, size_t n_poly, size_t L, const RowMa
     a.total_work = 0;
     a.src = nullptr;
     a.src_stride = a.src_off = 0;
+    static const long ldstw = env_long("MOAI_NTT_LDSTW", 1);
+    a.lds_twiddles = ldstw ? 1u : 0u;
     const int logn = c->logn;
     static const long coop_on = env_long("MOAI_NTT_COOP", 0);
     if (src)

@@ -88,6 +88,7 @@ struct NttArgs
     const uint64_t *src;
     uint32_t src_stride;
     uint32_t src_off;
+    uint32_t lds_twiddles; // forward contiguous pass: the first four stages' twiddles through LDS (MOAI_NTT_LDSTW=0: global loads)
 };
 
 // (q, q2) arguments of a tile function under MODE: the integer pair, or the bit patterns of (double q, 1/q)
@@ -434,10 +435,14 @@ struct StoreTile
 // M_NOGUARD: input below 20q (strided pass without guards), stages without guards, one Barrett step at
 // the end (cr1 = high word of floor(2^128/q)); M_GUARD: the reference's [0,4q) discipline; FP64 modes: doubles
 // in, canonical integers out (q, q2 carry the bit patterns of (double q, 1/q))
+// ldstw (or null): 240 entries of LDS beside lds2 for the twiddles of the first four stages -- fifteen per 256-block, shared by the
+// block's sixteen threads.  Every wave fetches the sixty of its own four blocks with ONE load per lane and reads them back from LDS
+// (broadcast reads, no s_barrier: the blocks of a wave are its own), instead of fifteen 16-byte global loads per thread issued one
+// or two ahead of the butterflies that use them.
 template <int LOGN, int MODE = M_GUARD, class StoreOp = StoreTile>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
-                                                const Tw *__restrict__ twb, uint64_t cr1, StoreOp store)
+                                                const Tw *__restrict__ twb, uint64_t cr1, StoreOp store, Tw *ldstw = nullptr)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
@@ -447,11 +452,25 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
     const uint32_t blk = (tile << 4) + b;
     const Tw *__restrict__ twbt = twb + (size_t)tile * (15 * 256);
 
+    if (ldstw)
+    {
+        const uint32_t lane = tid & 63u;
+        if (lane < 60u)
+        {
+            const uint32_t bb = ((tid >> 6) << 2) + lane / 15u, i = lane % 15u;       // block of this wave, slot 2^u - 1 + k
+            const uint32_t u = i == 0 ? 0u : (i < 3 ? 1u : (i < 7 ? 2u : 3u)), k = i - ((1u << u) - 1u);
+            ldstw[bb * 15u + i] = tw[(1u << (R1 + u)) + (((tile << 4) + bb) << u) + k];
+        }
+    }
     uint64_t x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {
         x[j] = base[(b << 8) | ((uint32_t)j << 4) | tl];
+    }
+    if (ldstw)
+    {
+        lds_wave_sync();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -462,7 +481,8 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
         {
             if (!(j & half))
             {
-                Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
+                Tw t = ldstw ? ldstw[b * 15u + ((1u << u) - 1u) + (uint32_t)(j >> (4 - u))]
+                             : tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
                 ct_bfly_stage<MODE>(x[j], x[j + half], t.w, t.wq, q, q2, 7 - u);
             }
         }
@@ -557,18 +577,18 @@ __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uin
 template <int LOGN, int MODE = M_GUARD>
 __device__ __forceinline__ void fwd_contig_tile(uint64_t *__restrict__ rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
-                                                const Tw *__restrict__ twb, uint64_t cr1 = 0)
+                                                const Tw *__restrict__ twb, uint64_t cr1 = 0, Tw *ldstw = nullptr)
 {
     StoreTile st;
     st.out = reinterpret_cast<ulonglong2 *>(rowp + ((size_t)tile << 12));
-    fwd_contig_tile<LOGN, MODE, StoreTile>(rowp, tile, tw, q, q2, lds2, tid, twb, cr1, st);
+    fwd_contig_tile<LOGN, MODE, StoreTile>(rowp, tile, tw, q, q2, lds2, tid, twb, cr1, st, ldstw);
 }
 
 template <int LOGN, int MODE = M_GUARD>
 __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
-    __shared__ ulonglong2 lds2[2048];
+    __shared__ ulonglong2 lds2[2048 + 240]; // the tile, and the first four stages' twiddles (fwd_contig_tile, ldstw)
     const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t pol = w % a.n_poly;
     const uint32_t rest = w / a.n_poly;
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
     const PrimeConst &pc = a.pc[prime];
     fwd_contig_tile<LOGN, MODE>(a.data + (((size_t)pol * a.L + r) << LOGN), tile, a.tw + ((size_t)prime << LOGN),
                                 mode_q<MODE>(pc), mode_q2<MODE>(pc), lds2, threadIdx.x,
-                                a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), pc.cr1);
+                                a.twb + (size_t)prime * ((size_t)TPR * 15 * 256), pc.cr1, a.lds_twiddles ? reinterpret_cast<Tw *>(lds2 + 2048) : nullptr);
 }
 
 // =====================================================================================================
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_contig(NttArgs a)
 template <int LOGN, int IM = 0>
 __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, const Tw *__restrict__ tw,
                                                 uint64_t q, uint64_t q2, ulonglong2 *lds2, const uint32_t tid,
-                                                const Tw *__restrict__ twb, const uint64_t *srcp = nullptr)
+                                                const Tw *__restrict__ twb, const uint64_t *srcp = nullptr, Tw *ldstw = nullptr)
 {
     constexpr int R1 = LOGN - 8;
     uint64_t *lds = reinterpret_cast<uint64_t *>(lds2);
@@ -608,6 +628,19 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
     for (int i = 0; i < 15; ++i)
     {
         tb[i] = twbt[((uint32_t)i << 8) + tid];
+    }
+    // ldstw (optional, unused by the kernels): the last four stages' twiddles through LDS like the forward pass's first four
+    // (fwd_contig_tile).  Measured on the bench's batch, same box: inverse 11.05 ms with it against 10.99 without -- this pass
+    // already has its first four stages' twiddles in registers before the tile arrives, and the extra 4 KiB of LDS buy nothing.
+    if (ldstw)
+    {
+        const uint32_t ln = tid & 63u;
+        if (ln < 60u)
+        {
+            const uint32_t bb = ((tid >> 6) << 2) + ln / 15u, i = ln % 15u;
+            const uint32_t u = i == 0 ? 0u : (i < 3 ? 1u : (i < 7 ? 2u : 3u)), k = i - ((1u << u) - 1u);
+            ldstw[bb * 15u + i] = tw[(1u << (R1 + u)) + (((tile << 4) + bb) << u) + k];
+        }
     }
     // the row read may be another buffer's (NttArgs::src) or the one written: the tile is whole in LDS before any of it is stored
     const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(srcp ? srcp + ((size_t)tile << 12) : base);
@@ -670,7 +703,8 @@ __device__ __forceinline__ void inv_contig_tile(uint64_t *rowp, uint32_t tile, c
         {
             if (!(j & half))
             {
-                Tw t = tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
+                Tw t = ldstw ? ldstw[b * 15u + ((1u << u) - 1u) + (uint32_t)(j >> (4 - u))]
+                             : tw[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (4 - u))];
                 gs_bfly_im<IM>(x[j], x[j + half], t.w, t.wq, q, q2, (u & 3) == 0); // FPN: sums folded in every fourth stage
             }
         }

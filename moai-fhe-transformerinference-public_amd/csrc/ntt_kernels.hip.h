@@ -316,20 +316,28 @@ __device__ __forceinline__ void strided_core(uint64_t (&x)[16], uint64_t *__rest
     }
 }
 
-template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD, bool PRE = false>
+// LDSTW (N = 2^16, `lds` with 512 more words): phase B's twiddles -- entries 16..255 of the table, the same for every tile -- are
+// copied into LDS, one 16-byte load per thread issued with the tile's own loads, and read from there behind the exchange
+template <int LOGN, class LoadOp = LoadIdentity, int MODE = M_GUARD, bool PRE = false, bool LDSTW = false>
 __device__ __forceinline__ void fwd_strided_tile(const uint64_t *__restrict__ inp, uint64_t *__restrict__ rowp, uint32_t tile,
                                                  const Tw *__restrict__ tw, uint64_t q, uint64_t q2, uint64_t *lds,
                                                  const uint32_t tid, LoadOp op = LoadOp(), const double *__restrict__ tw1 = nullptr)
 {
     constexpr uint32_t G = 1u << (12 - (LOGN - 8));
+    static_assert(!LDSTW || LOGN == 16, "the LDS copy holds the 256 entries phase B of N = 2^16 indexes");
+    Tw *ldstw = reinterpret_cast<Tw *>(lds + 4096);
     uint64_t x[16];
     strided_load_raw<LOGN>(inp + tile * G, tid, x);
+    if (LDSTW)
+    {
+        ldstw[tid] = tw[tid]; // visible to the workgroup behind the exchange's barrier
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j)
     {
         x[j] = op(x[j]);
     }
-    strided_core<LOGN, MODE, PRE, false>(x, rowp + tile * G, tw, q, q2, lds, tid, tw1);
+    strided_core<LOGN, MODE, PRE, false, LDSTW>(x, rowp + tile * G, tw, q, q2, lds, tid, tw1, LDSTW ? ldstw : nullptr);
 }
 
 // ITEMS consecutive tiles of one row by one workgroup, software-pipelined: the loads of tile i + 1 are issued before the
@@ -389,7 +397,9 @@ template <int LOGN, int MODE = M_GUARD>
 __global__ __launch_bounds__(256, (MODE == M_GUARD2 || MODE == M_LAZY8 || MODE == M_FPR || MODE == M_NOGUARD) ? 4 : 5) void ntt_fwd_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
-    __shared__ uint64_t lds[4096];
+    // the modes that run four workgroups per CU anyway take phase B's twiddles through LDS at N = 2^16 (4 KiB more)
+    constexpr bool LDSTW = LOGN == 16 && (MODE == M_GUARD2 || MODE == M_LAZY8 || MODE == M_FPR || MODE == M_NOGUARD);
+    __shared__ uint64_t lds[4096 + (LDSTW ? 512 : 0)];
     const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t tile = w % TPR;
     const uint32_t srow = w / TPR;                 // over n_poly * Lsel selected rows
@@ -405,12 +415,12 @@ __global__ __launch_bounds__(256, (MODE == M_GUARD2 || MODE == M_LAZY8 || MODE =
         LoadFp op;
         op.qd = pc.qd;
         op.qinv = pc.qinv;
-        fwd_strided_tile<LOGN, LoadFp, MODE>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), pc.qd, pc.qinv, lds, threadIdx.x, op);
+        fwd_strided_tile<LOGN, LoadFp, MODE, false, LDSTW>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), pc.qd, pc.qinv, lds, threadIdx.x, op);
     }
     else
     {
-        fwd_strided_tile<LOGN, LoadIdentity, MODE>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), mode_q<MODE>(pc), mode_q2<MODE>(pc), lds,
-                                                   threadIdx.x);
+        fwd_strided_tile<LOGN, LoadIdentity, MODE, false, LDSTW>(rowp, rowp, tile, a.tw + ((size_t)prime << LOGN), mode_q<MODE>(pc), mode_q2<MODE>(pc),
+                                                                 lds, threadIdx.x);
     }
 }
 

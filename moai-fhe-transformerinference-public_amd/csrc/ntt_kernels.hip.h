@@ -760,16 +760,28 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
     const uint64_t q2 = IM >= 2 ? pc->qinv : (LZ ? pc->n4q : pc->q2);
     uint64_t *__restrict__ row = rowp + tile * G;
 
+    // LDSTW (M_LAZY8 at N = 2^16: four workgroups per CU either way): phase B's twiddles -- entries 16..255 of the table, shared by
+    // the sixteen threads of a group -- through a copy in LDS (`lds` + 4096 words), as in the forward strided pass
+    constexpr bool LDSTW = LOGN == 16 && IM == 1;
+    Tw *ldstw = reinterpret_cast<Tw *>(lds + 4096);
     uint64_t x[16];
     if (RB > 0)
     {
         const uint32_t g = tid & (G - 1);
         const uint32_t th = tid >> GB;
+        if (LDSTW)
+        {
+            ldstw[tid] = tw[tid];
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j)
         {
             uint32_t t_ = (th << 4) | (uint32_t)j;
             x[j] = row[(t_ << 8) + g];
+        }
+        if (LDSTW)
+        {
+            lds_barrier();
         }
 #pragma unroll
         for (int s = R1 - 1; s >= 4; --s)
@@ -781,7 +793,7 @@ __device__ __forceinline__ void inv_strided_tile(uint64_t *__restrict__ rowp, ui
                 if (!(j & half))
                 {
                     uint32_t t_ = (th << 4) | (uint32_t)j;
-                    Tw t = tw[(1u << s) + (t_ >> (R1 - s))];
+                    Tw t = LDSTW ? ldstw[(1u << s) + (t_ >> (R1 - s))] : tw[(1u << s) + (t_ >> (R1 - s))];
                     gs_bfly_im<IM>(x[j], x[j + half], t.w, t.wq, q, q2, ((R1 - 1 - s) & 3) == 3); // stage number in this pass
                 }
             }
@@ -855,7 +867,7 @@ template <int LOGN, int IM = 0>
 __global__ __launch_bounds__(256, IM == 1 ? 4 : 5) void ntt_inv_strided(NttArgs a)
 {
     constexpr uint32_t TPR = 1u << (LOGN - 12);
-    __shared__ uint64_t lds[4096];
+    __shared__ uint64_t lds[4096 + ((LOGN == 16 && IM == 1) ? 512 : 0)]; // the exchange buffer (+ phase B's twiddles, inv_strided_tile)
     const uint32_t w = xcd_remap(blockIdx.x, a.total_work);
     const uint32_t tile = w % TPR;
     const uint32_t srow = w / TPR; // over n_poly * Lsel selected rows

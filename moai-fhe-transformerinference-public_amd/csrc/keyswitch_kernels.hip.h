@@ -186,6 +186,10 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
     constexpr uint32_t TPR8 = 1u << (LOGN - 11);
     __shared__ ulonglong2 lds_a2[1024];
     __shared__ ulonglong2 lds_b2[1024];
+    // FP64 modes: the seven twiddles of stages 0..2 per 256-block ([block][8] doubles) -- the same for every digit of the loop
+    // and for the block's 32 threads: fetched once per workgroup, read from LDS in every iteration instead of seven global loads
+    constexpr bool TW012 = MODE >= M_FPN;
+    __shared__ double lds_tw[TW012 ? 64 : 1];
     uint64_t *lds_a = reinterpret_cast<uint64_t *>(lds_a2);
     uint64_t *lds_b = reinterpret_cast<uint64_t *>(lds_b2);
 
@@ -236,6 +240,16 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
             twr[3 + i] = tw1[(1u << (R1 + 5)) + (blk << 5) + ((hi3 << 2) | (uint32_t)i)];
             twr[9 + i] = tw1[(1u << (R1 + 7)) + (blk << 7) + ((r << 2) | (uint32_t)i)];
         }
+    }
+    if (TW012)
+    {
+        if (tid0 < 64u && (tid0 & 7u) < 7u)
+        {
+            const uint32_t b_ = tid0 >> 3, i = tid0 & 7u;
+            const uint32_t u = i == 0 ? 0u : (i < 3 ? 1u : 2u);
+            lds_tw[tid0] = tw1[(1u << (R1 + u)) + ((((uint32_t)tile << 3) + b_) << u) + (i - ((1u << u) - 1u))];
+        }
+        lds_barrier(); // written by wave 0, read by all four
     }
     for (uint32_t J = j0; J < j1; ++J)
     {
@@ -299,7 +313,8 @@ __global__ __launch_bounds__(256, 4) void ks_contig_mac8(KsP2Args a)
                 {
                     if (MODE >= M_FPN)
                     {
-                        ct_bfly_fp1_sel(x[j], x[j + half], tw1[(1u << (R1 + u)) + (blk << u) + (uint32_t)(j >> (3 - u))], u2d(bq1), u2d(bq2), MODE == M_FPR && !(u & 1));
+                        ct_bfly_fp1_sel(x[j], x[j + half], lds_tw[(b << 3) + ((1u << u) - 1u) + (uint32_t)(j >> (3 - u))], u2d(bq1), u2d(bq2),
+                                        MODE == M_FPR && !(u & 1));
                     }
                     else
                     {
